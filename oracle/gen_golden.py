@@ -1,0 +1,511 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference (this container only).
+
+Test infrastructure, not product code.  Refers to the reference only by path
+(/root/reference); writes data-only fixtures into tests/golden/.  On the GPU
+box /root/reference does not exist and this script is never run there.
+
+Fixtures:
+  F1 reversi_random_games.npz   full random games, sizes 8/6/4, every ply
+  F2 reversi_positions.npz      arbitrary (unreachable) positions: legal masks,
+                                game-over, score, move results  (wrap probes)
+  F3 ttt_exhaustive.npz         all reachable TTT positions + double-line case
+  F4 ttt_csv.npz                the reference's tic_tac_toe_data.csv as arrays
+  F5 strings.json               __str__/__repr__ text, demo sequences
+  F6 illegal_moves.json         (position, move) pairs that raise ValueError
+  F7 mcts_twin.npz / .json      build-authored MCTS twin over the REFERENCE's
+                                board classes (every env transition inside the
+                                search is reference-computed)
+
+Run:  python oracle/gen_golden.py
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REF, "src/reversi/game_logic"))
+sys.path.insert(0, os.path.join(REF, "src/tic_tac_toe"))
+from reversi_board import ReversiBoard  # noqa: E402
+from tic_tac_toe_board import TicTacToeBoard  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+M64 = (1 << 64) - 1
+
+
+def rev_bits(board, player):
+    """bit 8*r+c for every cell equal to player (all sizes share the 8-stride)."""
+    b = 0
+    n = board.shape[0]
+    for r in range(n):
+        for c in range(n):
+            if board[r][c] == player:
+                b |= 1 << (8 * r + c)
+    return b
+
+
+def rev_mask(moves):
+    m = 0
+    for r, c in moves:
+        m |= 1 << (8 * r + c)
+    return m
+
+
+def ttt_bits(board, player):
+    b = 0
+    for r in range(3):
+        for c in range(3):
+            if board[r][c] == player:
+                b |= 1 << (3 * r + c)
+    return b
+
+
+# ---------------------------------------------------------------- F1
+def gen_f1():
+    random.seed(1234)
+    rows = []  # game, size, turn, to_move+1, x, o, legal, action(255=pass), flips, over_after
+    finals = []  # game, size, winner+1, n_plus, n_minus, passes, x_final, o_final
+    gid = 0
+    for size, ngames in ((8, 200), (6, 60), (4, 60)):
+        for _ in range(ngames):
+            b = ReversiBoard(size=size)
+            cur, over, turn, passes = 1, False, 0, 0
+            while not over:  # mirrors reversi_terminal.py:16-38
+                moves = b.generate_possible_moves(cur)
+                x, o = rev_bits(b.board, 1), rev_bits(b.board, -1)
+                if moves:
+                    r, c = random.choice(moves)
+                    nb = b.make_move(r, c, cur)
+                    flips = rev_bits(nb.board, cur) & ~rev_bits(b.board, cur) & ~(1 << (8 * r + c))
+                    act = 8 * r + c
+                    b = nb
+                else:
+                    flips, act = 0, 255
+                    passes += 1
+                over = b.is_game_over()
+                rows.append((gid, size, turn, cur + 1, x, o, rev_mask(moves), act, flips, int(over)))
+                cur *= -1
+                turn += 1
+            w, (n1, n2) = b.get_score()
+            finals.append((gid, size, w + 1, n1, n2, passes, rev_bits(b.board, 1), rev_bits(b.board, -1)))
+            gid += 1
+    rows = np.array(rows, dtype=np.uint64)
+    finals = np.array(finals, dtype=np.uint64)
+    np.savez_compressed(os.path.join(OUT, "reversi_random_games.npz"), rows=rows, finals=finals)
+    print("F1", rows.shape, finals.shape)
+
+
+# ---------------------------------------------------------------- F2
+def gen_f2():
+    rng = random.Random(99)
+    pos = []  # size, x, o, legal(+1), legal(-1), over, winner+1, n_plus, n_minus
+    moves = []  # pos_index, player(+1 -> 1, -1 -> 0), action, x_after, o_after
+    for size in (8, 6, 4):
+        for k in range(400):
+            b = ReversiBoard(size=size)
+            dens = rng.random()
+            bias = rng.random()
+            for r in range(size):
+                for c in range(size):
+                    u = rng.random()
+                    b.board[r][c] = 0 if u > dens else (1 if rng.random() < bias else -1)
+            if k % 7 == 0:  # dense edges: every a-/h-file and first/last row square occupied
+                for i in range(size):
+                    for (r, c) in ((i, 0), (i, size - 1), (0, i), (size - 1, i)):
+                        if rng.random() < 0.8:
+                            b.board[r][c] = rng.choice((1, -1))
+            l1 = b.generate_possible_moves(1)
+            l2 = b.generate_possible_moves(-1)
+            w, (n1, n2) = b.get_score()
+            pi = len(pos)
+            pos.append((size, rev_bits(b.board, 1), rev_bits(b.board, -1), rev_mask(l1), rev_mask(l2),
+                        int(b.is_game_over()), w + 1, n1, n2))
+            for player, lst in ((1, l1), (-1, l2)):
+                for (r, c) in lst:
+                    nb = b.make_move(r, c, player)
+                    moves.append((pi, 1 if player == 1 else 0, 8 * r + c, rev_bits(nb.board, 1),
+                                  rev_bits(nb.board, -1)))
+    np.savez_compressed(os.path.join(OUT, "reversi_positions.npz"),
+                        pos=np.array(pos, dtype=np.uint64), moves=np.array(moves, dtype=np.uint64))
+    print("F2", len(pos), len(moves))
+
+
+# ---------------------------------------------------------------- F3
+def gen_f3():
+    seen = {}
+    order = []
+    stack = [(TicTacToeBoard(), 1)]
+    while stack:
+        b, cur = stack.pop()
+        key = (ttt_bits(b.board, 1), ttt_bits(b.board, -1))
+        if key in seen:
+            continue
+        over, w = b.is_game_over()
+        legal = 0
+        for r, c in b.generate_possible_moves():
+            legal |= 1 << (3 * r + c)
+        seen[key] = 1
+        order.append((key[0], key[1], cur & 3, legal, int(over), 2 if w is None else w + 1))
+        if not over:
+            for r, c in b.generate_possible_moves():
+                stack.append((b.make_move(r, c, cur), -cur))
+    assert len(order) == 5478, len(order)
+    # unreachable: both players own a line -> (True, 1) (+1 is tested first)
+    b = TicTacToeBoard(np.array([[1, 1, 1], [-1, -1, -1], [0, 0, 0]]))
+    over, w = b.is_game_over()
+    extra = [(ttt_bits(b.board, 1), ttt_bits(b.board, -1), 1, 0b111000000, int(over), w + 1)]
+    b = TicTacToeBoard(np.array([[-1, 1, 0], [-1, 1, 0], [-1, 1, 0]]))
+    over, w = b.is_game_over()
+    extra.append((ttt_bits(b.board, 1), ttt_bits(b.board, -1), 1, 0b100100100, int(over), w + 1))
+    np.savez_compressed(os.path.join(OUT, "ttt_exhaustive.npz"),
+                        pos=np.array(order, dtype=np.int64), extra=np.array(extra, dtype=np.int64))
+    print("F3", len(order))
+
+
+# ---------------------------------------------------------------- F4
+def gen_f4():
+    import csv
+    st, ac = [], []
+    with open(os.path.join(REF, "tic_tac_toe_data.csv")) as f:
+        rd = csv.reader(f)
+        next(rd)
+        for row in rd:
+            st.append([int(v) for v in row[0].split()])
+            ac.append([int(v) for v in row[1].split()])
+    np.savez_compressed(os.path.join(OUT, "ttt_csv.npz"), states=np.array(st, dtype=np.int64),
+                        actions=np.array(ac, dtype=np.int64))
+    print("F4", len(st))
+
+
+# ---------------------------------------------------------------- F5 / F6
+def gen_f5_f6():
+    out = {"reversi": [], "ttt": []}
+    b = ReversiBoard(size=4)  # demo, reversi_board.py:92-99
+    seq = [(0, 2, 1), (0, 1, -1), (2, 0, 1)]
+    boards = [b]
+    for r, c, p in seq:
+        b = b.make_move(r, c, p)
+        boards.append(b)
+    for bb in boards + [ReversiBoard(), ReversiBoard(size=6)]:
+        out["reversi"].append({"size": bb.size, "board": bb.board.tolist(), "str": str(bb), "repr": repr(bb)})
+    out["reversi_demo"] = {"moves": seq, "final": b.board.tolist(),
+                           "valid_0_3_minus1": bool(b.is_valid_move(0, 3, -1))}
+    t = TicTacToeBoard()  # demo, tic_tac_toe_board.py:45-52
+    tb = [t]
+    for r, c, p in [(0, 0, 1), (0, 1, -1), (0, 2, 1)]:
+        t = t.make_move(r, c, p)
+        tb.append(t)
+    for tt in tb:
+        out["ttt"].append({"board": tt.board.tolist(), "str": str(tt), "repr": repr(tt)})
+    out["ttt_demo_valid_0_0"] = bool(t.is_valid_move(0, 0))
+    with open(os.path.join(OUT, "strings.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+    rng = random.Random(5)
+    ill = {"reversi": [], "ttt": []}
+    for size in (8, 6, 4):
+        b = ReversiBoard(size=size)
+        cur = 1
+        for _ in range(12):
+            mv = b.generate_possible_moves(cur)
+            bad = [(r, c) for r in range(-1, size + 1) for c in range(-1, size + 1) if (r, c) not in mv]
+            for (r, c) in rng.sample(bad, 6):
+                try:
+                    b.make_move(r, c, cur)
+                    raise AssertionError("reference accepted an illegal move")
+                except ValueError as e:
+                    ill["reversi"].append({"size": size, "board": b.board.tolist(), "player": cur,
+                                           "move": [r, c], "msg": str(e)})
+                except IndexError:
+                    pass  # negative/out-of-range probes never index: reference returns False first
+            if not mv:
+                break
+            b = b.make_move(*rng.choice(mv), cur)
+            cur = -cur
+    t = TicTacToeBoard()
+    cur = 1
+    for _ in range(5):
+        mv = t.generate_possible_moves()
+        for (r, c) in [(r, c) for r in range(-1, 4) for c in range(-1, 4) if (r, c) not in mv]:
+            try:
+                t.make_move(r, c, cur)
+                raise AssertionError
+            except ValueError as e:
+                ill["ttt"].append({"board": t.board.tolist(), "player": cur, "move": [r, c], "msg": str(e)})
+        t = t.make_move(*rng.choice(mv), cur)
+        cur = -cur
+    with open(os.path.join(OUT, "illegal_moves.json"), "w") as f:
+        json.dump(ill, f)
+    print("F5/F6", len(ill["reversi"]), len(ill["ttt"]))
+
+
+# ---------------------------------------------------------------- F7: MCTS twin
+f32 = np.float32
+
+
+def mix64(x):
+    x &= M64
+    x ^= x >> 33
+    x = (x * 0xFF51AFD7ED558CCD) & M64
+    x ^= x >> 33
+    x = (x * 0xC4CEB9FE1A85EC53) & M64
+    x ^= x >> 33
+    return x
+
+
+def rng_draw(seed, gid, ply):
+    h = mix64((seed * 0x9E3779B97F4A7C15 + gid) & M64)
+    return mix64(h ^ ((ply * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & M64))
+
+
+def expf_spec(x):
+    """exp for x <= 0, single float32 roundings, no fma."""
+    x = f32(x)
+    if x < f32(-87.0):
+        return f32(0.0)
+    t = x * f32(1.44269504)
+    n = np.floor(t + f32(0.5)).astype(np.float32)
+    r = x - n * f32(0.693359375)
+    r = r - n * f32(-2.12194440e-4)
+    p = f32(1.9875691500e-4)
+    for c in (1.3981999507e-3, 8.3334519073e-3, 4.1665795894e-2, 1.6666665459e-1, 5.0000001201e-1):
+        p = p * r + f32(c)
+    rr = r * r
+    p = p * rr
+    p = p + r
+    p = p + f32(1.0)
+    scale = np.array([(int(n) + 127) << 23], dtype=np.uint32).view(np.float32)[0]
+    return f32(p * scale)
+
+
+def eval_hash(own, opp, na):
+    h = mix64(((own * 0x9E3779B97F4A7C15) & M64) ^ mix64((opp + 0x632BE59BD9B4E019) & M64))
+    logits = []
+    for a in range(na):
+        q = mix64((h + a * 0xD6E8FEB86659FD93) & M64)
+        logits.append(f32((q >> 40) - (1 << 23)) * f32(1.0 / 4194304.0))
+    q = mix64(h ^ 0xA5A5A5A5A5A5A5A5)
+    v = f32((q >> 40) - (1 << 23)) * f32(1.0 / 8388608.0)
+    return logits, v
+
+
+class Twin:
+    """Sequential MCTS over the reference's board objects (spec M1-M5)."""
+
+    def __init__(self, game, eval_kind, c_puct=1.5):
+        self.game, self.eval_kind, self.c = game, eval_kind, f32(c_puct)
+        self.na = 9 if game == "ttt" else 65
+
+    # --- env through the reference only
+    def moves(self, b, p):
+        if self.game == "ttt":
+            return [3 * r + c for r, c in b.generate_possible_moves()]
+        return [8 * r + c for r, c in b.generate_possible_moves(p)]
+
+    def play(self, b, p, a):
+        if self.game == "ttt":
+            return b.make_move(a // 3, a % 3, p)
+        if a == 64:
+            return b
+        return b.make_move(a // 8, a % 8, p)
+
+    def terminal(self, b):
+        if self.game == "ttt":
+            over, w = b.is_game_over()
+            return over, (w if over else 0)
+        if b.is_game_over():
+            return True, b.get_score()[0]
+        return False, 0
+
+    def bits(self, b, p):
+        fn = ttt_bits if self.game == "ttt" else rev_bits
+        return fn(b.board, p), fn(b.board, -p)
+
+    def evaluate(self, b, p):
+        if self.eval_kind == "uniform":
+            return [f32(0.0)] * self.na, f32(0.0)
+        own, opp = self.bits(b, p)
+        return eval_hash(own, opp, self.na)
+
+    def expand(self, node):
+        logits, v = self.evaluate(node["b"], node["p"])
+        mv = self.moves(node["b"], node["p"])
+        if not mv:
+            node["edges"] = [{"a": 64, "N": 0, "W": f32(0), "P": f32(1), "child": None}]
+            return v
+        m = max(logits[a] for a in mv)
+        es = [expf_spec(logits[a] - m) for a in mv]
+        s = f32(0.0)
+        for e in es:
+            s = s + e
+        node["edges"] = [{"a": a, "N": 0, "W": f32(0), "P": f32(e / s), "child": None} for a, e in zip(mv, es)]
+        return v
+
+    def new_node(self, b, p):
+        over, w = self.terminal(b)
+        return {"b": b, "p": p, "term": over, "tv": w * p, "edges": None}
+
+    def simulate(self, root):
+        node, path = root, []
+        while True:
+            if node["term"]:
+                v = f32(node["tv"])
+                break
+            sumN = sum(e["N"] for e in node["edges"])
+            sq = np.sqrt(f32(max(sumN, 1)))
+            best, bests = None, f32(-np.inf)
+            for e in node["edges"]:
+                q = e["W"] / f32(e["N"]) if e["N"] > 0 else f32(0.0)
+                u = self.c * e["P"]
+                u = u * sq
+                u = u / (f32(1.0) + f32(e["N"]))
+                s = q + u
+                if s > bests:
+                    best, bests = e, s
+            path.append(best)
+            if best["child"] is not None:
+                node = best["child"]
+                continue
+            ch = self.new_node(self.play(node["b"], node["p"], best["a"]), -node["p"])
+            best["child"] = ch
+            v = f32(ch["tv"]) if ch["term"] else self.expand(ch)
+            break
+        val = -v
+        for e in reversed(path):
+            e["N"] += 1
+            e["W"] = f32(e["W"] + val)
+            val = -val
+
+    def search(self, b, p, sims):
+        root = self.new_node(b, p)
+        assert not root["term"]
+        self.expand(root)
+        for _ in range(sims):
+            self.simulate(root)
+        return root
+
+    def selfplay(self, gid, sims, temp_moves, openings, seed):
+        if self.game == "ttt":
+            b = TicTacToeBoard()
+        else:
+            b = ReversiBoard()
+        p, made, passes = 1, 0, 0
+        if self.game == "reversi" and openings:
+            k = gid % 12
+            for pick in (k // 3, k % 3):
+                a = self.moves(b, p)[pick]
+                b = self.play(b, p, a)
+                p, made = -p, made + 1
+        ex = []
+        while True:
+            root = self.search(b, p, sims)
+            sumN = sum(e["N"] for e in root["edges"])
+            pi = [f32(0.0)] * self.na
+            for e in root["edges"]:
+                pi[e["a"]] = f32(e["N"]) / f32(sumN)
+            if made < temp_moves:
+                r = rng_draw(seed, gid, made) % sumN
+                cum = 0
+                for e in root["edges"]:
+                    cum += e["N"]
+                    if cum > r:
+                        pick = e
+                        break
+            else:
+                pick, bn = root["edges"][0], 0
+                for e in root["edges"]:
+                    if e["N"] > bn:
+                        pick, bn = e, e["N"]
+            own, opp = self.bits(b, p)
+            ex.append((own, opp, pi, p, pick["a"]))
+            b = self.play(b, p, pick["a"])
+            p, made = -p, made + 1
+            over, w = self.terminal(b)
+            if over:
+                return ex, w, passes
+            if not self.moves(b, p):
+                p, passes = -p, passes + 1
+
+
+def gen_f7():
+    out = {}
+    meta = {"cases": []}
+    ci = 0
+
+    def add_search(game, eval_kind, b, p, sims, label):
+        nonlocal ci
+        tw = Twin(game, eval_kind)
+        root = tw.search(b, p, sims)
+        na = tw.na
+        N = np.zeros(na, np.uint32); W = np.zeros(na, np.float32); P = np.zeros(na, np.float32)
+        for e in root["edges"]:
+            N[e["a"]], W[e["a"]], P[e["a"]] = e["N"], e["W"], e["P"]
+        own, opp = tw.bits(b, p)
+        out[f"s{ci}_N"], out[f"s{ci}_W"], out[f"s{ci}_P"] = N, W, P
+        meta["cases"].append({"id": ci, "kind": "search", "game": game, "eval": eval_kind, "own": own,
+                              "opp": opp, "to_move": p, "sims": sims, "label": label})
+        ci += 1
+
+    # TTT searches
+    add_search("ttt", "uniform", TicTacToeBoard(), 1, 50, "empty, cfg2 setting")
+    add_search("ttt", "hash", TicTacToeBoard(), 1, 200, "empty")
+    t = TicTacToeBoard().make_move(1, 1, 1).make_move(0, 0, -1).make_move(2, 2, 1)
+    add_search("ttt", "hash", t, -1, 120, "mid")
+    add_search("ttt", "uniform", t, -1, 300, "mid, tree exhausts into terminals")
+    # Reversi searches (env = reference ReversiBoard)
+    add_search("reversi", "uniform", ReversiBoard(), 1, 40, "start")
+    add_search("reversi", "hash", ReversiBoard(), 1, 150, "start")
+    rnd = random.Random(77)
+    b, p = ReversiBoard(), 1
+    for k in range(52):  # late-game position: passes and terminals inside the tree
+        mv = b.generate_possible_moves(p)
+        if mv:
+            b = b.make_move(*rnd.choice(mv), p)
+        p = -p
+        if k in (20, 40, 51) and b.generate_possible_moves(p) and not b.is_game_over():
+            add_search("reversi", "hash", ReversiBoard(b), p, 120, f"random ply {k}")
+    # hand-made pass position inside the tree: X to move, after X's move O must pass
+    # self-play trajectories
+    def add_selfplay(game, eval_kind, gid, sims, temp_moves, openings, seed):
+        nonlocal ci
+        tw = Twin(game, eval_kind)
+        ex, w, passes = tw.selfplay(gid, sims, temp_moves, openings, seed)
+        out[f"g{ci}_own"] = np.array([e[0] for e in ex], dtype=np.uint64)
+        out[f"g{ci}_opp"] = np.array([e[1] for e in ex], dtype=np.uint64)
+        out[f"g{ci}_pi"] = np.array([e[2] for e in ex], dtype=np.float32)
+        out[f"g{ci}_mover"] = np.array([e[3] for e in ex], dtype=np.int8)
+        out[f"g{ci}_act"] = np.array([e[4] for e in ex], dtype=np.uint8)
+        meta["cases"].append({"id": ci, "kind": "selfplay", "game": game, "eval": eval_kind, "gid": gid,
+                              "sims": sims, "temp_moves": temp_moves, "openings": openings, "seed": seed,
+                              "winner": int(w), "passes": passes})
+        ci += 1
+
+    add_selfplay("ttt", "uniform", 0, 25, 0, 0, 0)      # BASELINE cfg 1 setting
+    add_selfplay("ttt", "hash", 3, 25, 0, 0, 0)
+    add_selfplay("ttt", "hash", 5, 40, 4, 0, 7)
+    add_selfplay("reversi", "hash", 0, 12, 0, 0, 0)
+    add_selfplay("reversi", "hash", 7, 10, 8, 1, 0)     # cfg 3 diversification rules
+    add_selfplay("reversi", "uniform", 10, 8, 8, 1, 3)
+    np.savez_compressed(os.path.join(OUT, "mcts_twin.npz"), **out)
+    with open(os.path.join(OUT, "mcts_twin.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    # expf spot values
+    xs = np.concatenate([np.linspace(-90, 0, 721), -np.logspace(-8, 1.9, 200)]).astype(np.float32)
+    ys = np.array([expf_spec(x) for x in xs], dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "expf_spec.npz"), x=xs, y=ys)
+    print("F7", ci, "cases")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7"]
+    if "f1" in which: gen_f1()
+    if "f2" in which: gen_f2()
+    if "f3" in which: gen_f3()
+    if "f4" in which: gen_f4()
+    if "f5" in which: gen_f5_f6()
+    if "f7" in which: gen_f7()
