@@ -1,0 +1,107 @@
+"""ctypes binding of libbz_hip.so (include/bz_abi.h).  No CPU fallback: if the
+library is missing this raises; batched calls need a HIP device."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libbz_hip.so")
+
+BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
+GAME_TTT, GAME_REVERSI = 0, 1
+EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_EXTERNAL = range(5)
+ST_RUNNING, ST_TERMINAL, ST_ILLEGAL, ST_MUST_PASS = range(4)
+PASS_ACTION = 64
+COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",
+                 "n_child_written", "n_env_steps", "n_net_leaves")
+
+u64, u32, i32, i64, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [("game", i32), ("n_games", i32), ("sims", i32), ("eval_kind", i32), ("c_puct", C.c_float),
+                ("temp_moves", i32), ("openings", i32), ("rounds", i32), ("t_max", i32), ("reserved", i32),
+                ("seed", u64), ("game_id_base", u64), ("game_id_stride", u64)]
+
+
+class EngineLayout(C.Structure):
+    _fields_ = [(n, i64) for n in ("ex_own", "ex_opp", "ex_pi", "ex_z", "ex_mover", "ex_act", "ex_len", "ex_winner",
+                                   "root_N", "root_W", "root_P", "leaf_own", "leaf_opp", "leaf_kind", "logits",
+                                   "value", "g_own", "g_opp", "g_to_move", "g_state", "counters")] + \
+               [("na", i32), ("t_max", i32)]
+
+
+_SIGS = {
+    "bz_abi_version": (i32, []),
+    "bz_last_error": (C.c_char_p, []),
+    "bz_device_count": (i32, []),
+    "bz_reversi_legal": (i32, [u64, u64, i32, C.POINTER(u64)]),
+    "bz_reversi_apply": (i32, [u64, u64, i32, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+    "bz_reversi_game_over": (i32, [u64, u64, i32, C.POINTER(i32)]),
+    "bz_reversi_score": (i32, [u64, u64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "bz_ttt_legal": (i32, [u32, u32, C.POINTER(u32)]),
+    "bz_ttt_apply": (i32, [u32, u32, i32, i32, C.POINTER(u32)]),
+    "bz_ttt_game_over": (i32, [u32, u32, C.POINTER(i32), C.POINTER(i32)]),
+    "bz_reversi_step_batch": (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "bz_reversi_legal_batch": (i32, [vp, vp, i64, vp, vp]),
+    "bz_ttt_step_batch": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "bz_net_param_count": (i64, [i32, i32, i32]),
+    "bz_net_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "bz_net_create": (i32, [i32, i32, i32, i32, vp, vp, i64, vp, C.POINTER(vp)]),
+    "bz_net_destroy": (i32, [vp]),
+    "bz_net_forward_f32": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "bz_net_forward_bf16": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "bz_engine_workspace_bytes": (i64, [C.POINTER(EngineCfg)]),
+    "bz_engine_create": (i32, [C.POINTER(EngineCfg), vp, i64, C.POINTER(vp)]),
+    "bz_engine_destroy": (i32, [vp]),
+    "bz_engine_get_layout": (i32, [vp, C.POINTER(EngineLayout)]),
+    "bz_engine_set_net": (i32, [vp, vp]),
+    "bz_engine_reset_games": (i32, [vp, vp]),
+    "bz_engine_set_roots": (i32, [vp, vp, vp, vp, vp]),
+    "bz_engine_search": (i32, [vp, vp]),
+    "bz_engine_root_begin": (i32, [vp, vp]),
+    "bz_engine_select": (i32, [vp, u32, vp]),
+    "bz_engine_evaluate": (i32, [vp, vp]),
+    "bz_engine_expand_backup": (i32, [vp, vp]),
+    "bz_engine_root_stats": (i32, [vp, vp]),
+    "bz_engine_play": (i32, [vp, i32, vp]),
+    "bz_engine_status": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
+    "bz_engine_reset_counters": (i32, [vp, vp]),
+}
+ABI_SYMBOLS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load libbz_hip.so; raise (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise RuntimeError(f"{SO} is missing: build it with `python -m betazero_amd.build` "
+                               "(there is no CPU fallback for the HIP engine)")
+        L = C.CDLL(SO)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.bz_abi_version() != 1:
+            raise RuntimeError("libbz_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return (lib().bz_last_error() or b"").decode()
+
+
+def check(rc):
+    if rc == BZ_OK:
+        return
+    msg = last_error()
+    if rc == BZ_EILLEGAL_MOVE:
+        raise ValueError("Invalid move")  # reversi_board.py:45, tic_tac_toe_board.py:25
+    raise RuntimeError(f"libbz_hip error {rc}: {msg}")
+
+
+def require_gpu():
+    if lib().bz_device_count() <= 0:
+        raise RuntimeError("betazero_amd: no HIP device visible; the batched engine has no CPU fallback")

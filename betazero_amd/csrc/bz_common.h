@@ -1,0 +1,32 @@
+// bz_common.h -- error plumbing shared by the translation units of libbz_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bz_abi.h"
+
+#define BZ_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace bz {
+void set_error(const char* fmt, ...);
+inline int32_t hip_fail(hipError_t e, const char* what) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return BZ_EHIP;
+}
+}  // namespace bz
+
+#define BZ_HIP(call)                                             \
+    do {                                                         \
+        hipError_t _e = (call);                                  \
+        if (_e != hipSuccess) return bz::hip_fail(_e, #call);    \
+    } while (0)
+#define BZ_LAUNCH_CHECK(name)                                    \
+    do {                                                         \
+        hipError_t _e = hipGetLastError();                       \
+        if (_e != hipSuccess) return bz::hip_fail(_e, name);     \
+    } while (0)
+#define BZ_REQUIRE(cond, msg)                                    \
+    do {                                                         \
+        if (!(cond)) { bz::set_error("%s", msg); return BZ_EINVAL; } \
+    } while (0)

@@ -1,0 +1,180 @@
+// bz_env.hip -- scalar rule entry points (host) and the batched board-env step
+// kernels (gfx950).  One game per lane: a wave steps 64 games, all loads and
+// stores are coalesced 8-byte (Reversi) / 2-byte (TTT) streams, the rule code is
+// pure 64-bit integer ALU (bz_rules.h) -- HBM-bound at 34+8 B per env step.
+#include <stdarg.h>
+
+#include "bz_common.h"
+#include "bz_rules.h"
+
+namespace bz {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace bz
+
+using namespace bz;
+
+BZ_EXPORT int32_t bz_abi_version(void) { return BZ_ABI_VERSION; }
+BZ_EXPORT const char* bz_last_error(void) { return bz::g_err; }
+BZ_EXPORT int32_t bz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+static bool size_ok(int32_t s) { return s == 4 || s == 6 || s == 8; }
+
+BZ_EXPORT int32_t bz_reversi_legal(uint64_t own, uint64_t opp, int32_t size, uint64_t* legal) {
+    BZ_REQUIRE(size_ok(size) && legal, "bz_reversi_legal: size must be 4, 6 or 8");
+    *legal = rev_legal(own, opp, rev_valid(size));
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_reversi_apply(uint64_t own, uint64_t opp, int32_t size, int32_t row, int32_t col,
+                                   uint64_t* own_after, uint64_t* opp_after, uint64_t* flips) {
+    BZ_REQUIRE(size_ok(size) && own_after && opp_after, "bz_reversi_apply: bad arguments");
+    if (row < 0 || row >= size || col < 0 || col >= size) { set_error("Invalid move"); return BZ_EILLEGAL_MOVE; }
+    u64 m = 1ULL << (8 * row + col);
+    if (!(rev_legal(own, opp, rev_valid(size)) & m)) { set_error("Invalid move"); return BZ_EILLEGAL_MOVE; }
+    u64 f = rev_flips(own, opp, m);
+    *own_after = own | m | f;
+    *opp_after = opp & ~f;
+    if (flips) *flips = f;
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_reversi_game_over(uint64_t a, uint64_t b, int32_t size, int32_t* over) {
+    BZ_REQUIRE(size_ok(size) && over, "bz_reversi_game_over: bad arguments");
+    u64 v = rev_valid(size);
+    *over = rev_legal(a, b, v) == 0 && rev_legal(b, a, v) == 0;
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_reversi_score(uint64_t x, uint64_t o, int32_t* winner, int32_t* n_x, int32_t* n_o) {
+    BZ_REQUIRE(winner, "bz_reversi_score: bad arguments");
+    int cx = popc64(x), co = popc64(o);
+    *winner = cx > co ? 1 : (co > cx ? -1 : 0);
+    if (n_x) *n_x = cx;
+    if (n_o) *n_o = co;
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_ttt_legal(uint32_t x, uint32_t o, uint32_t* legal) {
+    BZ_REQUIRE(legal, "bz_ttt_legal: bad arguments");
+    *legal = ~(x | o) & 0x1FFu;
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_ttt_apply(uint32_t own, uint32_t opp, int32_t row, int32_t col, uint32_t* own_after) {
+    BZ_REQUIRE(own_after, "bz_ttt_apply: bad arguments");
+    if (row < 0 || row >= 3 || col < 0 || col >= 3 || ((own | opp) >> (3 * row + col) & 1u)) {
+        set_error("Invalid move");
+        return BZ_EILLEGAL_MOVE;
+    }
+    *own_after = own | (1u << (3 * row + col));
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_ttt_game_over(uint32_t x, uint32_t o, int32_t* over, int32_t* winner) {
+    BZ_REQUIRE(over && winner, "bz_ttt_game_over: bad arguments");
+    int w;
+    *over = ttt_over(x & 0x1FF, o & 0x1FF, &w);
+    *winner = w;
+    return BZ_OK;
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ void __launch_bounds__(256) k_reversi_step(const u64* __restrict__ own, const u64* __restrict__ opp,
+                                                      const uint8_t* __restrict__ action, int64_t n,
+                                                      u64* __restrict__ own_next, u64* __restrict__ opp_next,
+                                                      u64* __restrict__ legal_next, uint8_t* __restrict__ status,
+                                                      int8_t* __restrict__ winner) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        u64 me = own[i], you = opp[i];
+        int a = action[i];
+        u64 lg = rev_legal8(me, you);
+        bool ok = a == kPass ? lg == 0 : (a < 64 && ((lg >> a) & 1ULL));
+        u64 cown = me, copp = you, nl = lg;
+        uint8_t st = BZ_ST_ILLEGAL;
+        int8_t w = 0;
+        if (ok) {
+            Reversi::apply(me, you, a, &cown, &copp);
+            nl = rev_legal8(cown, copp);
+            st = BZ_ST_RUNNING;
+            if (nl == 0) {
+                if (rev_legal8(copp, cown) == 0) {
+                    st = BZ_ST_TERMINAL;
+                    int d = popc64(copp) - popc64(cown);  // copp = the player who just moved
+                    w = d > 0 ? 1 : (d < 0 ? -1 : 0);
+                } else {
+                    st = BZ_ST_MUST_PASS;
+                }
+            }
+        }
+        own_next[i] = cown; opp_next[i] = copp; legal_next[i] = nl; status[i] = st; winner[i] = w;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reversi_legal(const u64* __restrict__ own, const u64* __restrict__ opp,
+                                                       int64_t n, u64* __restrict__ legal) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        legal[i] = rev_legal8(own[i], opp[i]);
+}
+
+__global__ void __launch_bounds__(256) k_ttt_step(const uint16_t* __restrict__ own, const uint16_t* __restrict__ opp,
+                                                  const uint8_t* __restrict__ action, const int8_t* __restrict__ to_move,
+                                                  int64_t n, uint16_t* __restrict__ own_next,
+                                                  uint16_t* __restrict__ opp_next, uint16_t* __restrict__ legal_next,
+                                                  uint8_t* __restrict__ status, int8_t* __restrict__ winner) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        u32 me = own[i] & 0x1FF, you = opp[i] & 0x1FF;
+        int a = action[i], tm = to_move[i];
+        bool ok = a < 9 && !(((me | you) >> a) & 1u);
+        u32 cown = me, copp = you;
+        uint8_t st = BZ_ST_ILLEGAL;
+        int w = 0;
+        if (ok) {
+            cown = you; copp = me | (1u << a);
+            u32 x = tm == 1 ? copp : cown, o = tm == 1 ? cown : copp;
+            st = ttt_over(x, o, &w) ? BZ_ST_TERMINAL : BZ_ST_RUNNING;
+        }
+        own_next[i] = (uint16_t)cown; opp_next[i] = (uint16_t)copp;
+        legal_next[i] = (uint16_t)(~(cown | copp) & 0x1FF);
+        status[i] = st; winner[i] = (int8_t)w;
+    }
+}
+
+static int grid_for(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));  // <= 256 CUs x 8 blocks, grid-stride the rest
+}
+
+BZ_EXPORT int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
+                                        uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
+                                        uint8_t* status, int8_t* winner, void* stream) {
+    BZ_REQUIRE(n >= 0 && own && opp && action && own_next && opp_next && legal_next && status && winner,
+               "bz_reversi_step_batch: null pointer");
+    if (n == 0) return BZ_OK;
+    hipLaunchKernelGGL(k_reversi_step, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, action, n,
+                       own_next, opp_next, legal_next, status, winner);
+    BZ_LAUNCH_CHECK("k_reversi_step");
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_reversi_legal_batch(const uint64_t* own, const uint64_t* opp, int64_t n, uint64_t* legal,
+                                         void* stream) {
+    BZ_REQUIRE(n >= 0 && own && opp && legal, "bz_reversi_legal_batch: null pointer");
+    if (n == 0) return BZ_OK;
+    hipLaunchKernelGGL(k_reversi_legal, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, n, legal);
+    BZ_LAUNCH_CHECK("k_reversi_legal");
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_ttt_step_batch(const uint16_t* own, const uint16_t* opp, const uint8_t* action,
+                                    const int8_t* to_move, int64_t n, uint16_t* own_next, uint16_t* opp_next,
+                                    uint16_t* legal_next, uint8_t* status, int8_t* winner, void* stream) {
+    BZ_REQUIRE(n >= 0 && own && opp && action && to_move && own_next && opp_next && legal_next && status && winner,
+               "bz_ttt_step_batch: null pointer");
+    if (n == 0) return BZ_OK;
+    hipLaunchKernelGGL(k_ttt_step, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, action, to_move,
+                       n, own_next, opp_next, legal_next, status, winner);
+    BZ_LAUNCH_CHECK("k_ttt_step");
+    return BZ_OK;
+}

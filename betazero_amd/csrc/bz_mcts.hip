@@ -1,0 +1,645 @@
+// bz_mcts.hip -- batched MCTS self-play engine for gfx950.
+//
+// One game per lane.  Per game the tree is a bump-allocated AoS pair in HBM:
+//   Node 32 B {own, opp, legal, edge0, info}     nodes[g][sims+2]
+//   Edge 16 B {N, W, P, child|action<<24}        edges[g][(sims+2)*MAXCH]
+// so one dwordx4 load brings an edge's (N, W, P, child) and a backup is one
+// 8-byte read-modify-write.  Per-game scalars are SoA across games (coalesced
+// per wave); the select path is stored depth-major path[d][g] (coalesced).
+//
+// Float discipline: compiled with -ffp-contract=off; PUCT / softmax / backup use
+// the single-rounding operation order of the oracle (oracle/bz_oracle.c), so
+// visit counts, moves and W/P/pi are bit-identical to it.
+//
+// Reference anchors: turn loop + pass rule reversi_terminal.py:16-38;
+// trajectory contract tic_tac_toe.py:13-34; canonical side-to-move states
+// generate_training_games.py:12-23.  MCTS itself is build-authored (the
+// reference has none).
+#include <new>
+
+#include "bz_common.h"
+#include "bz_math.h"
+#include "bz_rules.h"
+
+using namespace bz;
+
+namespace {
+
+struct __attribute__((aligned(16))) Node { u64 own, opp, legal; u32 edge0, info; };
+struct __attribute__((aligned(16))) Edge { u32 N; float W; float P; u32 ca; };
+static_assert(sizeof(Node) == 32 && sizeof(Edge) == 16, "layout");
+
+constexpr u32 kTerm = 1u << 8;
+enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2 };
+enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDED, CNT_CHILD_WRITTEN,
+       CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_N };
+enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_N = 4 };
+enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8 };
+
+struct EngineDev {
+    int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd;
+    float c_puct;
+    u64 seed, id_base, id_stride;
+    Node* nodes; Edge* edges;
+    u64 *g_own, *g_opp; int8_t* g_to_move; uint8_t* g_state; int32_t *g_moves, *g_nex, *g_round, *g_passes;
+    u32 *n_nodes, *n_edges, *path, *depth, *leaf_node;
+    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp;
+    float *logits, *value;
+    u64 *ex_own, *ex_opp; float* ex_pi; int8_t *ex_z, *ex_mover; uint8_t* ex_act; int32_t* ex_len; int8_t* ex_winner;
+    u32* root_N; float *root_W, *root_P;
+    u64* counters; u32* flags;
+};
+
+struct Cnt { u32 v[CNT_N]; };
+
+__device__ __forceinline__ void cnt_flush(const EngineDev& E, Cnt& c) {
+#pragma unroll
+    for (int k = 0; k < CNT_N; ++k) {
+        u32 x = c.v[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&E.counters[k], (unsigned long long)x);
+    }
+}
+
+// logits source for the expansion of one leaf
+struct LogitSrc {
+    int kind; u64 h; const float* row;
+    __device__ __forceinline__ float operator()(int a) const {
+        return kind == BZ_EVAL_UNIFORM ? 0.0f : (kind == BZ_EVAL_HASH ? hash_logit(h, a) : row[a]);
+    }
+};
+
+// M2: PUCT walk from the root; creates the child node behind the chosen
+// unexpanded edge (env step: apply + legal + terminal).
+template <class G>
+__device__ __forceinline__ void dev_select(const EngineDev& E, int g, u32 sim_idx, u32& n_nodes_g, u32& leaf,
+                                           int& kind, int& depth_out, float& tval, Cnt& c) {
+    Node* nodes = E.nodes + (size_t)g * E.ncap;
+    Edge* edges = E.edges + (size_t)g * E.ecap;
+    u32 node = 0, sumN = sim_idx;  // sum of the root's child visits == simulations done so far
+    int depth = 0;
+    c.v[CNT_SIMS]++;
+    for (;;) {
+        Node nd = nodes[node];
+        c.v[CNT_PATH_NODES]++;
+        if (nd.info & kTerm) {
+            kind = LEAF_TERMINAL; leaf = node; tval = (float)((int)((nd.info >> 9) & 3u) - 1);
+            break;
+        }
+        int n = (int)(nd.info & 0xFFu);
+        float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
+        const Edge* ed = edges + nd.edge0;
+        int best = 0; float bests = -__builtin_inff(); u32 bestN = 0, bestca = 0;
+        for (int i = 0; i < n; ++i) {
+            Edge e = ed[i];
+            float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
+            float u = E.c_puct * e.P;
+            u = u * sq;
+            u = fdiv(u, 1.0f + (float)e.N);
+            float s = q + u;
+            if (s > bests) { bests = s; best = i; bestN = e.N; bestca = e.ca; }
+        }
+        c.v[CNT_CHILD_SCORED] += (u32)n;
+        u32 eidx = nd.edge0 + (u32)best;
+        if (depth < E.maxd) E.path[(size_t)depth * E.B + g] = eidx;
+        else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
+        depth++;
+        u32 child = bestca & 0xFFFFFFu;
+        if (child) {  // children's visits of X == visits of the edge into X minus the creating one
+            node = child; sumN = bestN - 1u;
+            continue;
+        }
+        int act = (int)(bestca >> 24);
+        u64 cown, copp;
+        G::apply(nd.own, nd.opp, act, &cown, &copp);
+        c.v[CNT_ENV_STEPS]++;
+        u32 id = n_nodes_g++;
+        int tm = ((nd.info >> 11) & 1u) ? -1 : 1;  // child's mover = the other colour
+        u64 lg = G::legal(cown, copp);
+        int tv = 0;
+        bool term = G::terminal(cown, copp, tm, lg, &tv);
+        Node ch;
+        ch.own = cown; ch.opp = copp; ch.legal = term ? 0 : lg; ch.edge0 = 0;
+        ch.info = (term ? kTerm : 0u) | ((u32)(tv + 1) << 9) | ((tm == 1 ? 1u : 0u) << 11);
+        nodes[id] = ch;
+        edges[eidx].ca = id | ((u32)act << 24);
+        c.v[CNT_PATH_NODES]++;
+        leaf = id; kind = term ? LEAF_TERMINAL : LEAF_EVAL; tval = (float)tv;
+        break;
+    }
+    depth_out = depth;
+}
+
+// M3: masked softmax over the legal actions (ascending), edges bump-allocated
+template <class G>
+__device__ __forceinline__ void dev_expand(const EngineDev& E, int g, u32 leaf, const LogitSrc& ls, u32& n_edges_g,
+                                           Cnt& c) {
+    Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+    u64 legal = nd->legal;
+    u32 e0 = n_edges_g;
+    Edge* ed = E.edges + (size_t)g * E.ecap + e0;
+    int n = 0;
+    int room = E.ecap - (int)e0;
+    if (legal == 0) {  // forced pass: one edge, P = 1
+        if (room >= 1) { Edge e; e.N = 0; e.W = 0.0f; e.P = 1.0f; e.ca = (u32)kPass << 24; ed[0] = e; n = 1; }
+    } else {
+        float m = -__builtin_inff();
+        for (u64 l = legal; l; l &= l - 1) { float x = ls(ctz64(l)); if (x > m) m = x; }
+        float s = 0.0f;
+        for (u64 l = legal; l; l &= l - 1) s = s + expf_spec(ls(ctz64(l)) - m);
+        for (u64 l = legal; l && n < room; l &= l - 1) {
+            int a = ctz64(l);
+            Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(expf_spec(ls(a) - m), s); e.ca = (u32)a << 24;
+            ed[n++] = e;
+        }
+        if (popc64(legal) > room) atomicOr(&E.flags[FLAG_ERR], ERR_EDGE_OVERFLOW);
+    }
+    nd->edge0 = e0;
+    nd->info = (nd->info & ~0xFFu) | (u32)n;
+    n_edges_g = e0 + (u32)n;
+    c.v[CNT_EXPANDED]++;
+    c.v[CNT_CHILD_WRITTEN] += (u32)n;
+}
+
+// M4: W is stored for the mover at the parent, so the sign flips every ply
+__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int depth, float v, Cnt& c) {
+    Edge* edges = E.edges + (size_t)g * E.ecap;
+    float val = -v;
+    int dmax = depth < E.maxd ? depth : E.maxd;
+    for (int d = dmax - 1; d >= 0; --d) {
+        Edge* e = edges + E.path[(size_t)d * E.B + g];
+        u32 N = e->N; float W = e->W;
+        e->N = N + 1u;
+        e->W = W + val;
+        val = -val;
+    }
+    c.v[CNT_EDGES_BACKED] += (u32)dmax;
+}
+
+template <class G>
+__device__ __forceinline__ bool dev_root_init(const EngineDev& E, int g) {
+    u64 own = E.g_own[g], opp = E.g_opp[g];
+    int tm = E.g_to_move[g];
+    u64 lg = G::legal(own, opp);
+    int tv;
+    if (G::terminal(own, opp, tm, lg, &tv)) {
+        atomicOr(&E.flags[FLAG_ERR], ERR_TERMINAL_ROOT);
+        return false;
+    }
+    Node r; r.own = own; r.opp = opp; r.legal = lg; r.edge0 = 0; r.info = (tm == 1 ? 1u : 0u) << 11;
+    E.nodes[(size_t)g * E.ncap] = r;
+    return true;
+}
+
+// start position (+ fixed two-ply openings) of the game with global id gid
+template <class G>
+__device__ __forceinline__ void dev_start_game(const EngineDev& E, int g, int round) {
+    u64 own, opp;
+    G::start(&own, &opp);
+    int tm = 1, made = 0;
+    if (G::kGame == 1 && E.openings) {
+        u64 gid = E.id_base + (u64)round * E.id_stride + (u64)g;
+        int k = (int)(gid % 12ULL);
+        int pick[2] = {k / 3, k % 3};
+        for (int i = 0; i < 2; ++i) {
+            u64 l = G::legal(own, opp);
+            for (int j = 0; j < pick[i]; ++j) l &= l - 1;
+            u64 c0, c1;
+            G::apply(own, opp, ctz64(l), &c0, &c1);
+            own = c0; opp = c1; tm = -tm; made++;
+        }
+    }
+    E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm;
+    E.g_moves[g] = made; E.g_nex[g] = 0; E.g_round[g] = round; E.g_passes[g] = 0; E.g_state[g] = 0;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_reset_games(EngineDev E) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    dev_start_game<G>(E, g, 0);
+    for (int r = 0; r < E.rounds; ++r) { E.ex_len[(size_t)r * E.B + g] = -1; E.ex_winner[(size_t)r * E.B + g] = 0; }
+    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; }
+}
+
+__global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, const u64* opp, const int8_t* tm) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    E.g_own[g] = own[g]; E.g_opp[g] = opp[g]; E.g_to_move[g] = tm[g];
+    E.g_state[g] = 0; E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
+    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; }
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    uint8_t kind = LEAF_NONE;
+    if (E.g_state[g] == 0 && dev_root_init<G>(E, g)) {
+        kind = LEAF_EVAL;
+        E.n_nodes[g] = 1; E.n_edges[g] = 0; E.leaf_node[g] = 0; E.depth[g] = 0;
+    }
+    E.leaf_own[g] = E.g_own[g]; E.leaf_opp[g] = E.g_opp[g];
+    E.leaf_kind[g] = kind;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_select(EngineDev E, u32 sim_idx) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt c = {};
+    if (g < E.B) {
+        uint8_t kind8 = LEAF_NONE;
+        if (E.g_state[g] == 0 && E.leaf_kind[g] != LEAF_NONE) {
+            u32 nn = E.n_nodes[g], leaf; int kind, depth; float tv;
+            dev_select<G>(E, g, sim_idx, nn, leaf, kind, depth, tv, c);
+            E.n_nodes[g] = nn; E.leaf_node[g] = leaf; E.depth[g] = (u32)depth;
+            const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+            E.leaf_own[g] = nd->own; E.leaf_opp[g] = nd->opp;
+            kind8 = (uint8_t)kind;
+        }
+        E.leaf_kind[g] = kind8;
+    }
+    cnt_flush(E, c);
+}
+
+// synthetic evaluators as a separate step (used by the step-by-step API)
+template <class G>
+__global__ void __launch_bounds__(256) k_eval_synth(EngineDev E, int eval_kind) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B || E.leaf_kind[g] != LEAF_EVAL) return;
+    u64 h = hash_pos(E.leaf_own[g], E.leaf_opp[g]);
+    float* row = E.logits + (size_t)g * G::NA;
+    for (int a = 0; a < G::NA; ++a) row[a] = eval_kind == BZ_EVAL_HASH ? hash_logit(h, a) : 0.0f;
+    E.value[g] = eval_kind == BZ_EVAL_HASH ? hash_value(h) : 0.0f;
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_expand_backup(EngineDev E) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt c = {};
+    if (g < E.B) {
+        int kind = E.leaf_kind[g];
+        if (kind != LEAF_NONE) {
+            u32 leaf = E.leaf_node[g];
+            float v;
+            if (kind == LEAF_EVAL) {
+                u32 ne = E.n_edges[g];
+                LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + (size_t)g * G::NA;
+                dev_expand<G>(E, g, leaf, ls, ne, c);
+                E.n_edges[g] = ne;
+                v = E.value[g];
+                c.v[CNT_NET_LEAVES]++;
+            } else {
+                u32 info = E.nodes[(size_t)g * E.ncap + leaf].info;
+                v = (float)((int)((info >> 9) & 3u) - 1);
+            }
+            dev_backup(E, g, (int)E.depth[g], v, c);
+        }
+    }
+    cnt_flush(E, c);
+}
+
+// whole search in one launch for the synthetic evaluators (BASELINE cfg 2):
+// root expansion + sims x (select, expand, backup), no host round trip.
+template <class G>
+__global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt c = {};
+    if (g < E.B && E.g_state[g] == 0 && dev_root_init<G>(E, g)) {
+        u32 nn = 1, ne = 0;
+        LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
+        ls.h = hash_pos(E.g_own[g], E.g_opp[g]);
+        dev_expand<G>(E, g, 0, ls, ne, c);
+        for (int s = 0; s < E.sims; ++s) {
+            u32 leaf; int kind, depth; float v;
+            dev_select<G>(E, g, (u32)s, nn, leaf, kind, depth, v, c);
+            if (kind == LEAF_EVAL) {
+                const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+                ls.h = hash_pos(nd->own, nd->opp);
+                dev_expand<G>(E, g, leaf, ls, ne, c);
+                v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
+            }
+            dev_backup(E, g, depth, v, c);
+        }
+        E.n_nodes[g] = nn; E.n_edges[g] = ne;
+    }
+    cnt_flush(E, c);
+}
+
+template <class G>
+__global__ void __launch_bounds__(256) k_root_stats(EngineDev E) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B) return;
+    u32* rn = E.root_N + (size_t)g * G::NA; float* rw = E.root_W + (size_t)g * G::NA; float* rp = E.root_P + (size_t)g * G::NA;
+    for (int a = 0; a < G::NA; ++a) { rn[a] = 0; rw[a] = 0.0f; rp[a] = 0.0f; }
+    if (E.g_state[g] != 0) return;
+    Node r = E.nodes[(size_t)g * E.ncap];
+    const Edge* ed = E.edges + (size_t)g * E.ecap + r.edge0;
+    for (int i = 0; i < (int)(r.info & 0xFFu); ++i) {
+        Edge e = ed[i];
+        int a = (int)(e.ca >> 24);
+        rn[a] = e.N; rw[a] = e.W; rp[a] = e.P;
+    }
+}
+
+// M5 + the reference's turn loop: pi, move choice, example row, env step,
+// pass rule (reversi_terminal.py:31-35), terminal handling, z back-fill.
+template <class G>
+__global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B || E.g_state[g] != 0) return;
+    Node root = E.nodes[(size_t)g * E.ncap];
+    const Edge* ed = E.edges + (size_t)g * E.ecap + root.edge0;
+    int n = (int)(root.info & 0xFFu);
+    u32 sumN = 0;
+    for (int i = 0; i < n; ++i) sumN += ed[i].N;
+    int round = E.g_round[g], nex = E.g_nex[g], made = E.g_moves[g], tm = E.g_to_move[g];
+    size_t rowbase = ((size_t)round * E.B + g) * E.t_max;
+    if (nex >= E.t_max) { atomicOr(&E.flags[FLAG_ERR], ERR_EXAMPLE_OVERFLOW); E.g_state[g] = 1; return; }
+    size_t row = rowbase + nex;
+    float* pi = E.ex_pi + row * G::NA;
+    for (int a = 0; a < G::NA; ++a) pi[a] = 0.0f;
+    int pick = 0;
+    if (made < E.temp_moves) {  // tau = 1: sample ~ N with the counter RNG (seed, game id, moves made)
+        u64 gid = E.id_base + (u64)round * E.id_stride + (u64)g;
+        u64 rr = rng_draw(E.seed, gid, (u64)made) % (u64)sumN, cum = 0;
+        bool found = false;
+        for (int i = 0; i < n; ++i) {
+            u32 N = ed[i].N;
+            pi[ed[i].ca >> 24] = fdiv((float)N, (float)sumN);
+            cum += N;
+            if (!found && cum > rr) { pick = i; found = true; }
+        }
+    } else {  // tau = 0: argmax N, ties -> lowest action
+        u32 bn = 0;
+        for (int i = 0; i < n; ++i) {
+            u32 N = ed[i].N;
+            pi[ed[i].ca >> 24] = fdiv((float)N, (float)sumN);
+            if (N > bn) { bn = N; pick = i; }
+        }
+    }
+    int a = (int)(ed[pick].ca >> 24);
+    E.ex_own[row] = root.own; E.ex_opp[row] = root.opp; E.ex_mover[row] = (int8_t)tm; E.ex_act[row] = (uint8_t)a;
+    nex++;
+    u64 own, opp;
+    G::apply(root.own, root.opp, a, &own, &opp);
+    tm = -tm; made++;
+    u64 lg = G::legal(own, opp);
+    int tv;
+    if (G::terminal(own, opp, tm, lg, &tv)) {
+        int w = tv * tm;
+        for (int t = 0; t < nex; ++t) E.ex_z[rowbase + t] = (int8_t)(w * E.ex_mover[rowbase + t]);
+        E.ex_len[(size_t)round * E.B + g] = nex;
+        E.ex_winner[(size_t)round * E.B + g] = (int8_t)w;
+        atomicAdd(&E.flags[FLAG_FINISHED], 1u);
+        if (restart && round + 1 < E.rounds) { dev_start_game<G>(E, g, round + 1); return; }
+        E.g_state[g] = 1;
+    } else if (lg == 0) {  // the next mover cannot move: flip the side again
+        u64 t = own; own = opp; opp = t; tm = -tm;
+        E.g_passes[g]++;
+    }
+    E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm; E.g_moves[g] = made; E.g_nex[g] = nex;
+}
+
+__global__ void __launch_bounds__(256) k_count_active(EngineDev E) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 act = (g < E.B && E.g_state[g] == 0) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) act += __shfl_xor(act, o, 64);
+    if ((threadIdx.x & 63) == 0 && act) atomicAdd(&E.flags[FLAG_ACTIVE], act);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- host side
+struct bz_engine {
+    bz_engine_cfg cfg;
+    bz_engine_layout lay;
+    EngineDev dev;
+    bz_net* net;
+    int64_t bytes;
+};
+
+namespace {
+struct Carver {
+    int64_t off = 0;
+    int64_t take(int64_t bytes) { int64_t o = off; off += (bytes + 255) & ~int64_t(255); return o; }
+};
+
+struct Offsets {
+    int64_t nodes, edges, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
+        path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
+        ex_act, ex_len, ex_winner, root_N, root_W, root_P, counters, flags, total;
+    int ncap, ecap, na, maxd;
+};
+
+bool cfg_ok(const bz_engine_cfg* c) {
+    return c && (c->game == BZ_GAME_TTT || c->game == BZ_GAME_REVERSI) && c->n_games > 0 && c->sims >= 1 &&
+           c->sims < (1 << 20) && c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_EXTERNAL && c->rounds >= 1 &&
+           c->t_max >= 1;
+}
+
+Offsets carve(const bz_engine_cfg& c) {
+    Offsets o{};
+    bool ttt = c.game == BZ_GAME_TTT;
+    o.na = ttt ? TicTacToe::NA : Reversi::NA;
+    o.maxd = ttt ? TicTacToe::MAXD : Reversi::MAXD;
+    o.ncap = c.sims + 2;
+    o.ecap = (c.sims + 2) * (ttt ? TicTacToe::MAXCH : Reversi::MAXCH);
+    int64_t B = c.n_games, R = c.rounds, T = c.t_max;
+    Carver k;
+    o.nodes = k.take(B * o.ncap * (int64_t)sizeof(Node));
+    o.edges = k.take(B * o.ecap * (int64_t)sizeof(Edge));
+    o.g_own = k.take(B * 8); o.g_opp = k.take(B * 8); o.g_to_move = k.take(B); o.g_state = k.take(B);
+    o.g_moves = k.take(B * 4); o.g_nex = k.take(B * 4); o.g_round = k.take(B * 4); o.g_passes = k.take(B * 4);
+    o.n_nodes = k.take(B * 4); o.n_edges = k.take(B * 4);
+    o.path = k.take((int64_t)o.maxd * B * 4); o.depth = k.take(B * 4); o.leaf_node = k.take(B * 4);
+    o.leaf_kind = k.take(B); o.leaf_own = k.take(B * 8); o.leaf_opp = k.take(B * 8);
+    o.logits = k.take(B * o.na * 4); o.value = k.take(B * 4);
+    o.ex_own = k.take(R * B * T * 8); o.ex_opp = k.take(R * B * T * 8); o.ex_pi = k.take(R * B * T * o.na * 4);
+    o.ex_z = k.take(R * B * T); o.ex_mover = k.take(R * B * T); o.ex_act = k.take(R * B * T);
+    o.ex_len = k.take(R * B * 4); o.ex_winner = k.take(R * B);
+    o.root_N = k.take(B * o.na * 4); o.root_W = k.take(B * o.na * 4); o.root_P = k.take(B * o.na * 4);
+    o.counters = k.take(16 * 8); o.flags = k.take(FLAG_N * 4);
+    o.total = k.off;
+    return o;
+}
+
+template <class T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+inline dim3 grid_of(int B) { return dim3((B + 255) / 256); }
+}  // namespace
+
+#define BZ_DISPATCH(e, KERNEL, stream, ...)                                                             \
+    do {                                                                                                \
+        if ((e)->cfg.game == BZ_GAME_TTT)                                                               \
+            hipLaunchKernelGGL(KERNEL<TicTacToe>, grid_of((e)->dev.B), dim3(256), 0, (hipStream_t)(stream), \
+                               __VA_ARGS__);                                                            \
+        else                                                                                            \
+            hipLaunchKernelGGL(KERNEL<Reversi>, grid_of((e)->dev.B), dim3(256), 0, (hipStream_t)(stream),   \
+                               __VA_ARGS__);                                                            \
+        BZ_LAUNCH_CHECK(#KERNEL);                                                                       \
+    } while (0)
+
+BZ_EXPORT int64_t bz_engine_workspace_bytes(const bz_engine_cfg* cfg) {
+    if (!cfg_ok(cfg)) { set_error("bz_engine_workspace_bytes: bad config"); return -1; }
+    return carve(*cfg).total;
+}
+
+BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t bytes, bz_engine** out) {
+    BZ_REQUIRE(cfg_ok(cfg) && ws && out, "bz_engine_create: bad config or null pointer");
+    if (bz_device_count() <= 0) { set_error("bz_engine_create: no HIP device (the engine has no CPU path)"); return BZ_ENOGPU; }
+    Offsets o = carve(*cfg);
+    if (bytes < o.total) { set_error("bz_engine_create: workspace too small (%lld < %lld)", (long long)bytes, (long long)o.total); return BZ_ENOMEM; }
+    BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_engine_create: workspace must be 256-byte aligned");
+    bz_engine* e = new (std::nothrow) bz_engine();
+    if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
+    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total;
+    EngineDev& d = e->dev;
+    d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
+    d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
+    d.c_puct = cfg->c_puct; d.seed = cfg->seed; d.id_base = cfg->game_id_base; d.id_stride = cfg->game_id_stride;
+    d.nodes = at<Node>(ws, o.nodes); d.edges = at<Edge>(ws, o.edges);
+    d.g_own = at<u64>(ws, o.g_own); d.g_opp = at<u64>(ws, o.g_opp); d.g_to_move = at<int8_t>(ws, o.g_to_move);
+    d.g_state = at<uint8_t>(ws, o.g_state); d.g_moves = at<int32_t>(ws, o.g_moves); d.g_nex = at<int32_t>(ws, o.g_nex);
+    d.g_round = at<int32_t>(ws, o.g_round); d.g_passes = at<int32_t>(ws, o.g_passes);
+    d.n_nodes = at<u32>(ws, o.n_nodes); d.n_edges = at<u32>(ws, o.n_edges); d.path = at<u32>(ws, o.path);
+    d.depth = at<u32>(ws, o.depth); d.leaf_node = at<u32>(ws, o.leaf_node); d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
+    d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
+    d.logits = at<float>(ws, o.logits); d.value = at<float>(ws, o.value);
+    d.ex_own = at<u64>(ws, o.ex_own); d.ex_opp = at<u64>(ws, o.ex_opp); d.ex_pi = at<float>(ws, o.ex_pi);
+    d.ex_z = at<int8_t>(ws, o.ex_z); d.ex_mover = at<int8_t>(ws, o.ex_mover); d.ex_act = at<uint8_t>(ws, o.ex_act);
+    d.ex_len = at<int32_t>(ws, o.ex_len); d.ex_winner = at<int8_t>(ws, o.ex_winner);
+    d.root_N = at<u32>(ws, o.root_N); d.root_W = at<float>(ws, o.root_W); d.root_P = at<float>(ws, o.root_P);
+    d.counters = at<u64>(ws, o.counters); d.flags = at<u32>(ws, o.flags);
+    bz_engine_layout& l = e->lay;
+    l.ex_own = o.ex_own; l.ex_opp = o.ex_opp; l.ex_pi = o.ex_pi; l.ex_z = o.ex_z; l.ex_mover = o.ex_mover;
+    l.ex_act = o.ex_act; l.ex_len = o.ex_len; l.ex_winner = o.ex_winner; l.root_N = o.root_N; l.root_W = o.root_W;
+    l.root_P = o.root_P; l.leaf_own = o.leaf_own; l.leaf_opp = o.leaf_opp; l.leaf_kind = o.leaf_kind;
+    l.logits = o.logits; l.value = o.value; l.g_own = o.g_own; l.g_opp = o.g_opp; l.g_to_move = o.g_to_move;
+    l.g_state = o.g_state; l.counters = o.counters; l.na = o.na; l.t_max = cfg->t_max;
+    *out = e;
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_destroy(bz_engine* e) { delete e; return BZ_OK; }
+
+BZ_EXPORT int32_t bz_engine_get_layout(const bz_engine* e, bz_engine_layout* out) {
+    BZ_REQUIRE(e && out, "bz_engine_get_layout: null pointer");
+    *out = e->lay;
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_set_net(bz_engine* e, bz_net* net) {
+    BZ_REQUIRE(e, "bz_engine_set_net: null engine");
+    e->net = net;
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_reset_counters(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_HIP(hipMemsetAsync(e->dev.counters, 0, 16 * 8, (hipStream_t)stream));
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_reset_games(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_HIP(hipMemsetAsync(e->dev.counters, 0, 16 * 8, (hipStream_t)stream));
+    BZ_DISPATCH(e, k_reset_games, stream, e->dev);
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_set_roots(bz_engine* e, const uint64_t* own, const uint64_t* opp, const int8_t* to_move,
+                                      void* stream) {
+    BZ_REQUIRE(e && own && opp && to_move, "bz_engine_set_roots: null pointer");
+    hipLaunchKernelGGL(k_set_roots, grid_of(e->dev.B), dim3(256), 0, (hipStream_t)stream, e->dev, own, opp, to_move);
+    BZ_LAUNCH_CHECK("k_set_roots");
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_root_begin(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_DISPATCH(e, k_root_begin, stream, e->dev);
+    return BZ_OK;
+}
+
+static int32_t select_step(bz_engine* e, uint32_t sim_idx, void* stream) {
+    BZ_DISPATCH(e, k_select, stream, e->dev, sim_idx);
+    return BZ_OK;
+}
+
+/* sim_index = number of simulations already completed in this search (the root's visit sum) */
+BZ_EXPORT int32_t bz_engine_select(bz_engine* e, uint32_t sim_index, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    return select_step(e, sim_index, stream);
+}
+
+BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    int ek = e->cfg.eval_kind;
+    if (ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) {
+        BZ_DISPATCH(e, k_eval_synth, stream, e->dev, ek);
+        return BZ_OK;
+    }
+    if (ek == BZ_EVAL_EXTERNAL) return BZ_OK;
+    BZ_REQUIRE(e->net, "bz_engine_evaluate: eval_kind needs a net (bz_engine_set_net)");
+    BZ_REQUIRE(e->cfg.game == BZ_GAME_REVERSI, "bz_engine_evaluate: the conv net is 8x8 Reversi only");
+    if (ek == BZ_EVAL_NET_F32)
+        return bz_net_forward_f32(e->net, e->dev.leaf_own, e->dev.leaf_opp, e->dev.B, e->dev.logits, e->dev.value, stream);
+    return bz_net_forward_bf16(e->net, e->dev.leaf_own, e->dev.leaf_opp, e->dev.B, e->dev.logits, e->dev.value, stream);
+}
+
+BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_DISPATCH(e, k_expand_backup, stream, e->dev);
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    int ek = e->cfg.eval_kind;
+    if (ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) {
+        BZ_DISPATCH(e, k_search_fused, stream, e->dev, ek);
+        return BZ_OK;
+    }
+    BZ_REQUIRE(ek != BZ_EVAL_EXTERNAL, "bz_engine_search: BZ_EVAL_EXTERNAL callers drive the step API");
+    int32_t rc;
+    if ((rc = bz_engine_root_begin(e, stream)) != BZ_OK) return rc;
+    if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
+    if ((rc = bz_engine_expand_backup(e, stream)) != BZ_OK) return rc;
+    for (int s = 0; s < e->cfg.sims; ++s) {
+        if ((rc = select_step(e, (uint32_t)s, stream)) != BZ_OK) return rc;
+        if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
+        if ((rc = bz_engine_expand_backup(e, stream)) != BZ_OK) return rc;
+    }
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_root_stats(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_DISPATCH(e, k_root_stats, stream, e->dev);
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_DISPATCH(e, k_play, stream, e->dev, (int)restart);
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
+                                   int32_t* error_flags) {
+    BZ_REQUIRE(e, "null engine");
+    hipStream_t s = (hipStream_t)stream;
+    BZ_HIP(hipMemsetAsync(e->dev.flags + FLAG_ACTIVE, 0, 4, s));
+    hipLaunchKernelGGL(k_count_active, grid_of(e->dev.B), dim3(256), 0, s, e->dev);
+    BZ_LAUNCH_CHECK("k_count_active");
+    u32 h[FLAG_N];
+    BZ_HIP(hipMemcpyAsync(h, e->dev.flags, sizeof(h), hipMemcpyDeviceToHost, s));
+    BZ_HIP(hipStreamSynchronize(s));
+    if (n_active) *n_active = (int32_t)h[FLAG_ACTIVE];
+    if (games_finished) *games_finished = (int64_t)h[FLAG_FINISHED];
+    if (error_flags) *error_flags = (int32_t)h[FLAG_ERR];
+    return BZ_OK;
+}
+

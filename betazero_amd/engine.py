@@ -1,0 +1,223 @@
+"""SelfPlayEngine: torch-owned workspace + the bz_engine C ABI (batched MCTS
+self-play on one GPU), and self_play(), the batched counterpart of the
+reference's data-generation loop (SL/generate_training_games.py:25-38)."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (EVAL_EXTERNAL, EVAL_HASH, EVAL_NET_BF16, EVAL_NET_F32, EVAL_UNIFORM, GAME_REVERSI, GAME_TTT,
+                   EngineCfg, EngineLayout)
+
+_GAMES = {"ttt": GAME_TTT, "tic_tac_toe": GAME_TTT, "reversi": GAME_REVERSI, GAME_TTT: GAME_TTT,
+          GAME_REVERSI: GAME_REVERSI}
+_EVALS = {"uniform": EVAL_UNIFORM, "hash": EVAL_HASH, "net_f32": EVAL_NET_F32, "net_bf16": EVAL_NET_BF16,
+          "external": EVAL_EXTERNAL}
+
+
+def _u64(t):
+    """int64 tensor holding uint64 bit patterns -> numpy uint64"""
+    return t.cpu().numpy().view(np.uint64)
+
+
+@dataclass
+class Examples:
+    """(s, pi, z) rows.  own/opp: side-to-move canonical bitboards (the bitboard
+    form of generate_training_games.py:17-18); pi [n, NA]; z in {-1,0,+1} for the
+    mover; game = global game id; ply = row index inside its game."""
+    own: np.ndarray
+    opp: np.ndarray
+    pi: np.ndarray
+    z: np.ndarray
+    mover: np.ndarray
+    act: np.ndarray
+    game: np.ndarray
+    ply: np.ndarray
+    size: int
+
+    def __len__(self):
+        return self.own.shape[0]
+
+    def states(self):
+        """canonical boards [n, size, size] int8: +1 = side to move, -1 = opponent"""
+        s = self.size
+        stride = 3 if s == 3 else 8
+        sh = np.array([[stride * r + c for c in range(s)] for r in range(s)], dtype=np.uint64)
+        a = ((self.own[:, None, None] >> sh) & np.uint64(1)).astype(np.int8)
+        b = ((self.opp[:, None, None] >> sh) & np.uint64(1)).astype(np.int8)
+        return a - b
+
+
+class SelfPlayEngine:
+    def __init__(self, game, n_games, sims, evaluator="uniform", net=None, c_puct=1.5, temp_moves=0, openings=0,
+                 seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0"):
+        _lib.require_gpu()
+        L = _lib.lib()
+        self.game = _GAMES[game]
+        self.device = torch.device(device)
+        t_max = 9 if self.game == GAME_TTT else 64
+        self.cfg = EngineCfg(self.game, n_games, sims, _EVALS[evaluator], c_puct, temp_moves, openings, rounds, t_max,
+                             0, seed, game_id_base, n_games if game_id_stride is None else game_id_stride)
+        nbytes = L.bz_engine_workspace_bytes(C.byref(self.cfg))
+        if nbytes < 0:
+            raise RuntimeError(_lib.last_error())
+        self.ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+        self._pad = (-self.ws.data_ptr()) & 255
+        h = C.c_void_p()
+        _lib.check(L.bz_engine_create(C.byref(self.cfg), self.ws.data_ptr() + self._pad, nbytes, C.byref(h)))
+        self.h = h
+        self.lay = EngineLayout()
+        _lib.check(L.bz_engine_get_layout(self.h, C.byref(self.lay)))
+        self.B, self.sims, self.rounds, self.na, self.t_max = n_games, sims, rounds, self.lay.na, t_max
+        self.net = net
+        if net is not None:
+            _lib.check(L.bz_engine_set_net(self.h, net.h))
+
+    # ---- views into the workspace
+    def _view(self, off, dtype, shape):
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        o = self._pad + off
+        return self.ws[o:o + n].view(dtype).view(*shape)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _call(self, fn, *args):
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self.h, *args, self._stream()))
+
+    # ---- ABI passthroughs
+    def reset_games(self):
+        self._call(_lib.lib().bz_engine_reset_games)
+
+    def set_roots(self, own, opp, to_move):
+        own = torch.as_tensor(np.asarray(own, dtype=np.uint64).view(np.int64)).to(self.device)
+        opp = torch.as_tensor(np.asarray(opp, dtype=np.uint64).view(np.int64)).to(self.device)
+        tm = torch.as_tensor(np.asarray(to_move, dtype=np.int8)).to(self.device)
+        assert own.numel() == self.B
+        self._call(_lib.lib().bz_engine_set_roots, own.data_ptr(), opp.data_ptr(), tm.data_ptr())
+        torch.cuda.current_stream(self.device).synchronize()  # keep own/opp/tm alive until consumed
+
+    def search(self):
+        self._call(_lib.lib().bz_engine_search)
+
+    def root_begin(self):
+        self._call(_lib.lib().bz_engine_root_begin)
+
+    def select(self, sim_index):
+        self._call(_lib.lib().bz_engine_select, sim_index)
+
+    def evaluate(self):
+        self._call(_lib.lib().bz_engine_evaluate)
+
+    def expand_backup(self):
+        self._call(_lib.lib().bz_engine_expand_backup)
+
+    def play(self, restart=False):
+        self._call(_lib.lib().bz_engine_play, int(restart))
+
+    def reset_counters(self):
+        self._call(_lib.lib().bz_engine_reset_counters)
+
+    def status(self):
+        a, f, e = C.c_int32(), C.c_int64(), C.c_int32()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bz_engine_status(self.h, self._stream(), C.byref(a), C.byref(f), C.byref(e)))
+        if e.value:
+            raise RuntimeError(f"bz_engine error flags 0x{e.value:x}")
+        return a.value, f.value
+
+    def root_stats(self):
+        self._call(_lib.lib().bz_engine_root_stats)
+        shp = (self.B, self.na)
+        N = self._view(self.lay.root_N, torch.int32, shp).cpu().numpy().view(np.uint32)
+        W = self._view(self.lay.root_W, torch.float32, shp).cpu().numpy()
+        P = self._view(self.lay.root_P, torch.float32, shp).cpu().numpy()
+        return N, W, P
+
+    def counters(self):
+        c = self._view(self.lay.counters, torch.int64, (16,)).cpu().numpy()
+        return dict(zip(_lib.COUNTER_NAMES, (int(v) for v in c[:8])))
+
+    # leaf buffers for BZ_EVAL_EXTERNAL callers (torch tensors aliasing the workspace)
+    def leaf_buffers(self):
+        return {"own": self._view(self.lay.leaf_own, torch.int64, (self.B,)),
+                "opp": self._view(self.lay.leaf_opp, torch.int64, (self.B,)),
+                "kind": self._view(self.lay.leaf_kind, torch.uint8, (self.B,)),
+                "logits": self._view(self.lay.logits, torch.float32, (self.B, self.na)),
+                "value": self._view(self.lay.value, torch.float32, (self.B,))}
+
+    def positions(self):
+        return (_u64(self._view(self.lay.g_own, torch.int64, (self.B,))),
+                _u64(self._view(self.lay.g_opp, torch.int64, (self.B,))),
+                self._view(self.lay.g_to_move, torch.int8, (self.B,)).cpu().numpy(),
+                self._view(self.lay.g_state, torch.uint8, (self.B,)).cpu().numpy())
+
+    # ---- example buffers
+    def example_tensors(self):
+        """fixed-capacity device tensors [rounds, B, t_max, ...] (what the all-gather ships)"""
+        R, B, T = self.rounds, self.B, self.t_max
+        return {"own": self._view(self.lay.ex_own, torch.int64, (R, B, T)),
+                "opp": self._view(self.lay.ex_opp, torch.int64, (R, B, T)),
+                "pi": self._view(self.lay.ex_pi, torch.float32, (R, B, T, self.na)),
+                "z": self._view(self.lay.ex_z, torch.int8, (R, B, T)),
+                "mover": self._view(self.lay.ex_mover, torch.int8, (R, B, T)),
+                "act": self._view(self.lay.ex_act, torch.uint8, (R, B, T)),
+                "len": self._view(self.lay.ex_len, torch.int32, (R, B)),
+                "winner": self._view(self.lay.ex_winner, torch.int8, (R, B))}
+
+    def examples(self):
+        return pack_examples({k: v.cpu().numpy() for k, v in self.example_tensors().items()},
+                             int(self.cfg.game_id_base), int(self.cfg.game_id_stride),
+                             3 if self.game == GAME_TTT else 8)
+
+    def winners(self):
+        t = self.example_tensors()
+        return t["winner"].cpu().numpy(), t["len"].cpu().numpy()
+
+    def run_iteration(self, max_plies=None):
+        """play every slot's game to termination (one self-play iteration)"""
+        self.reset_games()
+        plies = 0
+        limit = max_plies or (12 if self.game == GAME_TTT else 140)
+        while True:
+            self.search()
+            self.play(False)
+            plies += 1
+            active, _ = self.status()
+            if active == 0 or plies >= limit:
+                return plies
+
+    def __del__(self):
+        try:
+            _lib.lib().bz_engine_destroy(self.h)
+        except Exception:
+            pass
+
+
+def pack_examples(t, id_base, id_stride, size):
+    """[R,B,T,...] fixed-capacity arrays -> compact Examples (finished games only)"""
+    R, B, T = t["own"].shape
+    ln = t["len"]
+    valid = (np.arange(T)[None, None, :] < ln[:, :, None])
+    r, b, k = np.nonzero(valid)
+    gid = id_base + r.astype(np.int64) * id_stride + b
+    return Examples(own=t["own"][r, b, k].view(np.uint64), opp=t["opp"][r, b, k].view(np.uint64), pi=t["pi"][r, b, k],
+                    z=t["z"][r, b, k], mover=t["mover"][r, b, k], act=t["act"][r, b, k], game=gid,
+                    ply=k.astype(np.int32), size=size)
+
+
+def self_play(game, n_games, sims, net=None, seed=0, evaluator=None, temp_moves=0, openings=0, c_puct=1.5,
+              device="cuda:0", game_id_base=0, game_id_stride=None):
+    """Play n_games concurrent self-play games to the end on one GPU and return
+    (s, pi, z): canonical states int8 [n, size, size], visit-count policies
+    f32 [n, NA], outcomes for the mover int8 [n] -- plus the Examples object."""
+    if evaluator is None:
+        evaluator = "net_bf16" if net is not None else "uniform"
+    eng = SelfPlayEngine(game, n_games, sims, evaluator, net, c_puct, temp_moves, openings, seed, 1, game_id_base,
+                         game_id_stride, device)
+    eng.run_iteration()
+    ex = eng.examples()
+    return ex.states(), ex.pi, ex.z, ex

@@ -1,0 +1,69 @@
+"""Player plug-in point (reference: src/tic_tac_toe/players.py:6-9,
+src/reversi/players/reversi_players.py:5-8) and the MCTS player that fills it."""
+import random
+from abc import ABC, abstractmethod
+
+import numpy as np
+
+
+class Player(ABC):
+    @abstractmethod
+    def get_move(self, board):
+        pass
+
+
+class ReversiPlayer(ABC):
+    @abstractmethod
+    def get_move(self, board):
+        pass
+
+
+class RandomPlayer(Player):  # players.py:25-27
+    def get_move(self, board):
+        return random.choice(board.generate_possible_moves())
+
+
+class ReversiRandomPlayer(ReversiPlayer):  # reversi_players.py:26-32
+    def __init__(self, symbol):
+        self.symbol = symbol
+
+    def get_move(self, board):
+        moves = board.generate_possible_moves(self.symbol)
+        return random.choice(moves) if moves else (None, None)
+
+
+class MCTSPlayer(Player):
+    """get_move(board) -> (row, col) by one GPU search (PUCT, `sims` simulations)
+    from `board` with `symbol` to move; plays argmax visit count (ties -> lowest
+    action).  Works for TicTacToeBoard and 8x8 ReversiBoard; evaluator "net_bf16"
+    / "net_f32" need a betazero_amd.net.DeviceNet (Reversi)."""
+
+    def __init__(self, symbol, sims=800, net=None, evaluator=None, c_puct=1.5, device="cuda:0"):
+        self.symbol, self.sims, self.net, self.c_puct, self.device = symbol, sims, net, c_puct, device
+        self.evaluator = evaluator or ("net_bf16" if net is not None else "uniform")
+        self._eng = {}
+        self.last_visits = None
+
+    def _engine(self, game):
+        from .engine import SelfPlayEngine
+        if game not in self._eng:
+            self._eng[game] = SelfPlayEngine(game, 1, self.sims, self.evaluator, self.net, self.c_puct,
+                                             device=self.device)
+        return self._eng[game]
+
+    def get_move(self, board):
+        game = "reversi" if hasattr(board, "size") else "ttt"
+        if game == "reversi" and board.size != 8:
+            raise ValueError("MCTSPlayer supports 8x8 Reversi boards")
+        own, opp = board.bits(self.symbol)
+        eng = self._engine(game)
+        eng.set_roots([own], [opp], [self.symbol])
+        eng.search()
+        N, _, _ = eng.root_stats()
+        eng.status()  # raises on engine error flags (e.g. terminal root)
+        self.last_visits = N[0]
+        a = int(np.argmax(N[0]))  # first maximum = lowest action
+        if N[0][a] == 0 or a == 64:
+            return (None, None)  # mover has no move (reversi_players.py:32)
+        n = 3 if game == "ttt" else 8
+        return a // n, a % n

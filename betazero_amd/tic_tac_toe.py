@@ -1,0 +1,98 @@
+"""API-compatible TicTacToeBoard (reference: src/tic_tac_toe/tic_tac_toe_board.py:4-43),
+TicTacToeHeadless (tic_tac_toe.py:6-34) and process_game_positions
+(SL/generate_training_games.py:12-23)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_W3 = np.array([[1 << (3 * r + c) for c in range(3)] for r in range(3)], dtype=np.int64)
+
+
+class TicTacToeBoard:
+    def __init__(self, board=None):
+        self.board = np.zeros((3, 3), dtype=int) if board is None else np.copy(board)
+
+    def bits(self, player=1):
+        x = int((_W3 * (self.board == 1)).sum())
+        o = int((_W3 * (self.board == -1)).sum())
+        return (x, o) if player == 1 else (o, x)
+
+    def __str__(self):  # tic_tac_toe_board.py:7-15
+        out_str = ""
+        for i, row in enumerate(self.board):
+            if i != 0:
+                out_str += '\n'
+            out_str += ' ' + ' | '.join(['X' if cell == 1 else 'O' if cell == -1 else ' ' for cell in row]) + ' '
+            if i != 2:
+                out_str += '\n---+---+---'
+        return out_str
+
+    def __repr__(self):
+        return f"{self.board}"
+
+    def is_valid_move(self, row, col):
+        if not (0 <= row < 3 and 0 <= col < 3):
+            return False
+        x, o = self.bits()
+        out = C.c_uint32()
+        _lib.check(_lib.lib().bz_ttt_legal(x, o, C.byref(out)))
+        return bool(out.value >> (3 * row + col) & 1)
+
+    def make_move(self, row, col, player):
+        x, o = self.bits()
+        out = C.c_uint32()
+        _lib.check(_lib.lib().bz_ttt_apply(x, o, int(row), int(col), C.byref(out)))  # ValueError("Invalid move")
+        new_board = TicTacToeBoard(self.board)
+        new_board.board[row][col] = player  # the reference stores whatever `player` is
+        return new_board
+
+    def is_game_over(self):
+        x, o = self.bits()
+        over, w = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().bz_ttt_game_over(x, o, C.byref(over), C.byref(w)))
+        return (True, w.value) if over.value else (False, None)
+
+    def generate_possible_moves(self):
+        x, o = self.bits()
+        out = C.c_uint32()
+        _lib.check(_lib.lib().bz_ttt_legal(x, o, C.byref(out)))
+        return [(i, j) for i in range(3) for j in range(3) if out.value >> (3 * i + j) & 1]
+
+
+class TicTacToeHeadless:
+    """tic_tac_toe.py:6-34: records board.board before every move plus the final
+    one and returns (game_positions, winner)."""
+
+    def __init__(self, player1, player2):
+        self.board = TicTacToeBoard()
+        self.players = {1: player1, -1: player2}
+        self.current_player = 1
+        self.game_positions = []
+
+    def play(self):
+        game_over, winner = False, None
+        while not game_over:
+            self.game_positions.append(self.board.board)
+            player = self.players[self.current_player]
+            row, col = player.get_move(self.board)
+            try:
+                self.board = self.board.make_move(row, col, self.current_player)
+            except ValueError as e:
+                raise ValueError(f"Invalid move: {e}")
+            game_over, winner = self.board.is_game_over()
+            self.current_player *= -1
+            if game_over:
+                self.game_positions.append(self.board.board)
+        return self.game_positions, winner
+
+
+def process_game_positions(positions):
+    """generate_training_games.py:12-23 on numpy: side-to-move canonical states
+    (position i times (-1)**i) and one-hot actions -p[i+1] - p[i]."""
+    p = np.stack(positions).astype(np.int64)
+    sign = (-1) ** np.arange(p.shape[0])
+    p = p * sign.reshape((-1,) + (1,) * (p.ndim - 1))
+    actions = -p[1:] - p[:-1]
+    return p[:-1], actions

@@ -1,0 +1,201 @@
+/*
+ * bz_abi.h -- C ABI of libbz_hip.so, the MI355X (gfx950) self-play engine that
+ * drops in behind BetaZero's Python Game / Player API.
+ *
+ * The reference (whaiproject/BetaZero) is pure Python and has NO FFI: the seams
+ * this ABI sits behind are duck-typed Python interfaces.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * root).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain C types only; every function returns int32_t status
+ *    (BZ_OK or a BZ_E* code) and never throws / aborts; bz_last_error() gives
+ *    the thread-local message of the last failure.
+ *  - Batched entry points take RAW DEVICE POINTERS (torch.Tensor.data_ptr()),
+ *    element counts and a hipStream_t passed as void* (0 = default stream).
+ *    They are asynchronous on that stream.  The library never allocates or
+ *    frees device memory the caller sees: the caller passes a workspace sized
+ *    by the matching *_workspace_bytes() query.
+ *  - Bitboards: Reversi bit = 8*row+col for every board size (4, 6, 8);
+ *    Tic-tac-toe bit = 3*row+col.  "own" = stones of the side to move,
+ *    "opp" = the other side (the side-to-move canonical form of
+ *    src/tic_tac_toe/SL/generate_training_games.py:17-18).
+ *  - Action index = size*row+col as in the reference's CSV flattening
+ *    (generate_training_games.py:42-43); on 8x8 that equals the bit index.
+ *    Action 64 = "pass" exists only inside the search tree.
+ */
+#ifndef BZ_ABI_H
+#define BZ_ABI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZ_ABI_VERSION 1
+
+enum { BZ_OK = 0, BZ_EINVAL = 1, BZ_EILLEGAL_MOVE = 2, BZ_EHIP = 3, BZ_ENOMEM = 4, BZ_ENOGPU = 5,
+       BZ_ESTATE = 6 };
+enum { BZ_GAME_TTT = 0, BZ_GAME_REVERSI = 1 };
+/* leaf evaluators: uniform priors + v=0 (BASELINE cfg 2), synthetic hash (P,v)
+ * (tree-kernel parity runs), the conv net in exact-fp32 parity mode, the conv
+ * net on bf16 MFMA (the product path), or caller-filled logits/value. */
+enum { BZ_EVAL_UNIFORM = 0, BZ_EVAL_HASH = 1, BZ_EVAL_NET_F32 = 2, BZ_EVAL_NET_BF16 = 3,
+       BZ_EVAL_EXTERNAL = 4 };
+#define BZ_PASS_ACTION 64
+
+int32_t bz_abi_version(void);
+const char* bz_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only host); never fails */
+int32_t bz_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Scalar rules (host side of the same __host__ __device__ rule functions    */
+/* the kernels use).  Back the API-compatible single-board classes.          */
+/* ------------------------------------------------------------------------ */
+/* ReversiBoard.generate_possible_moves / is_valid_move
+ *   src/reversi/game_logic/reversi_board.py:25-41, 87-88 */
+int32_t bz_reversi_legal(uint64_t own, uint64_t opp, int32_t size, uint64_t* legal);
+/* ReversiBoard.make_move  reversi_board.py:43-59.  BZ_EILLEGAL_MOVE where the
+ * reference raises ValueError("Invalid move").  Outputs are NOT swapped:
+ * own_after = mover's stones after the move. */
+int32_t bz_reversi_apply(uint64_t own, uint64_t opp, int32_t size, int32_t row, int32_t col,
+                         uint64_t* own_after, uint64_t* opp_after, uint64_t* flips);
+/* ReversiBoard.is_game_over  reversi_board.py:61-65 */
+int32_t bz_reversi_game_over(uint64_t a, uint64_t b, int32_t size, int32_t* over);
+/* ReversiBoard.get_score  reversi_board.py:67-85 (x = +1 stones, o = -1 stones) */
+int32_t bz_reversi_score(uint64_t x, uint64_t o, int32_t* winner, int32_t* n_x, int32_t* n_o);
+/* TicTacToeBoard.generate_possible_moves  src/tic_tac_toe/tic_tac_toe_board.py:42-43 */
+int32_t bz_ttt_legal(uint32_t x, uint32_t o, uint32_t* legal);
+/* TicTacToeBoard.make_move  tic_tac_toe_board.py:20-29 */
+int32_t bz_ttt_apply(uint32_t own, uint32_t opp, int32_t row, int32_t col, uint32_t* own_after);
+/* TicTacToeBoard.is_game_over  tic_tac_toe_board.py:31-40 (+1 tested before -1);
+ * *winner is 1/-1/0 and meaningful only when *over != 0 */
+int32_t bz_ttt_game_over(uint32_t x, uint32_t o, int32_t* over, int32_t* winner);
+
+/* ------------------------------------------------------------------------ */
+/* Batched board-env step (device).  One game per lane.                      */
+/* Replaces one iteration of the turn loop in                                */
+/*   ReversiTerminal.play  reversi_terminal.py:19-35                         */
+/*   TicTacToeHeadless.play  src/tic_tac_toe/tic_tac_toe.py:16-27            */
+/* for n games at once.                                                      */
+/* ------------------------------------------------------------------------ */
+/* status codes written by the step kernels */
+enum { BZ_ST_RUNNING = 0, BZ_ST_TERMINAL = 1, BZ_ST_ILLEGAL = 2, BZ_ST_MUST_PASS = 3 };
+/* in : own/opp of the mover, action[n] (0..63, or 64 = pass)
+ * out: position seen by the NEXT mover (own_next = next mover's stones),
+ *      legal_next = next mover's legal mask, status (above; on ILLEGAL the
+ *      outputs repeat the inputs), winner = +1/-1/0 for the player who just
+ *      moved (valid when TERMINAL).  BZ_ST_MUST_PASS: game not over but the
+ *      next mover has no move (the driver flips the side, reversi_terminal.py:32). */
+int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
+                              uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
+                              uint8_t* status, int8_t* winner, void* stream);
+int32_t bz_reversi_legal_batch(const uint64_t* own, const uint64_t* opp, int64_t n, uint64_t* legal,
+                               void* stream);
+/* Tic-tac-toe: to_move[n] = absolute colour (+1/-1) of the mover; winner is the
+ * ABSOLUTE colour (+1/-1/0) exactly as TicTacToeBoard.is_game_over returns it. */
+int32_t bz_ttt_step_batch(const uint16_t* own, const uint16_t* opp, const uint8_t* action,
+                          const int8_t* to_move, int64_t n, uint16_t* own_next, uint16_t* opp_next,
+                          uint16_t* legal_next, uint8_t* status, int8_t* winner, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Policy/value net (build-authored architecture, SURVEY.md 8(d) "net";      */
+/* the calling convention generalises AIPlayer.get_move players.py:84-98:    */
+/* side-to-move canonical input, logits out, legality masked by the caller)  */
+/* ------------------------------------------------------------------------ */
+typedef struct bz_net bz_net;
+/* flat fp32 parameter vector, torch layouts, in this order:
+ *  stem.w[C][2][3][3] stem.b[C] { c1.w[C][C][3][3] c1.b[C] c2.w[C][C][3][3] c2.b[C] } x NB
+ *  pol.w[2][C] pol.b[2] polfc.w[65][128] polfc.b[65]
+ *  val.w[1][C] val.b[1] v1.w[VH][64] v1.b[VH] v2.w[1][VH] v2.b[1] */
+int64_t bz_net_param_count(int32_t C, int32_t NB, int32_t VH);
+int64_t bz_net_workspace_bytes(int32_t C, int32_t NB, int32_t VH, int32_t max_batch);
+/* params_host: host pointer.  Repacks + uploads weights into the workspace
+ * (synchronises the stream once). */
+int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_batch, const float* params_host,
+                      void* workspace, int64_t workspace_bytes, void* stream, bz_net** out);
+int32_t bz_net_destroy(bz_net* net);
+/* own/opp: device u64[n]; logits: device f32[n][65]; value: device f32[n].
+ * _f32: exact parity mode (k-ordered fmaf chains == oracle bit for bit).
+ * _bf16: MFMA path (bf16 activations/weights, fp32 accumulate); needs C==128. */
+int32_t bz_net_forward_f32(bz_net* net, const uint64_t* own, const uint64_t* opp, int32_t n,
+                           float* logits, float* value, void* stream);
+int32_t bz_net_forward_bf16(bz_net* net, const uint64_t* own, const uint64_t* opp, int32_t n,
+                            float* logits, float* value, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Batched MCTS self-play engine.  The plug-in point it fills is             */
+/*   Player.get_move(board)  src/tic_tac_toe/players.py:6-9,                 */
+/*   ReversiPlayer.get_move  src/reversi/players/reversi_players.py:5-8      */
+/* (one search per call) and, batched, the game loops cited above plus the   */
+/* example extraction of generate_training_games.py:12-38.                   */
+/* ------------------------------------------------------------------------ */
+typedef struct bz_engine bz_engine;
+typedef struct bz_engine_cfg {
+    int32_t game;        /* BZ_GAME_* */
+    int32_t n_games;     /* concurrent game slots B on this GPU */
+    int32_t sims;        /* simulations per move */
+    int32_t eval_kind;   /* BZ_EVAL_* */
+    float c_puct;        /* 1.5 in every BASELINE config */
+    int32_t temp_moves;  /* moves_made < temp_moves -> sample ~ N (tau=1), else argmax N */
+    int32_t openings;    /* Reversi: first 2 plies from the 12 fixed openings (game_id % 12) */
+    int32_t rounds;      /* example-buffer depth: slot s plays games s, s+stride, ... (>=1) */
+    int32_t t_max;       /* example rows per game (64 Reversi, 9 TTT) */
+    int32_t reserved;
+    uint64_t seed;
+    uint64_t game_id_base;   /* global id of slot 0, round 0 (= rank * n_games) */
+    uint64_t game_id_stride; /* id distance between rounds (= world_size * n_games) */
+} bz_engine_cfg;
+
+/* offsets (bytes, from the workspace base) of the caller-visible arrays */
+typedef struct bz_engine_layout {
+    int64_t ex_own, ex_opp;   /* u64 [rounds][B][t_max]  side-to-move canonical s */
+    int64_t ex_pi;            /* f32 [rounds][B][t_max][NA]  pi = N/sum N            */
+    int64_t ex_z;             /* i8  [rounds][B][t_max]  outcome for the mover       */
+    int64_t ex_mover, ex_act; /* i8 / u8 [rounds][B][t_max]                          */
+    int64_t ex_len;           /* i32 [rounds][B]  rows valid (-1 = game not finished) */
+    int64_t ex_winner;        /* i8  [rounds][B]  absolute winner                    */
+    int64_t root_N, root_W, root_P; /* u32/f32/f32 [B][NA] filled by bz_engine_root_stats */
+    int64_t leaf_own, leaf_opp;     /* u64 [B]   positions awaiting evaluation       */
+    int64_t leaf_kind;              /* u8  [B]   1 = needs (logits,value)             */
+    int64_t logits, value;          /* f32 [B][NA], f32 [B]  evaluator outputs        */
+    int64_t g_own, g_opp;           /* u64 [B] current positions                      */
+    int64_t g_to_move, g_state;     /* i8 / u8 [B]  (state: 0 active, 1 finished)     */
+    int64_t counters;               /* u64 [16] work counters           */
+    int32_t na, t_max;
+} bz_engine_layout;
+
+int64_t bz_engine_workspace_bytes(const bz_engine_cfg* cfg);
+int32_t bz_engine_create(const bz_engine_cfg* cfg, void* workspace, int64_t workspace_bytes,
+                         bz_engine** out);
+int32_t bz_engine_destroy(bz_engine* e);
+int32_t bz_engine_get_layout(const bz_engine* e, bz_engine_layout* out);
+int32_t bz_engine_set_net(bz_engine* e, bz_net* net);
+/* start every slot at the game's start position (round 0) */
+int32_t bz_engine_reset_games(bz_engine* e, void* stream);
+/* load arbitrary root positions (MCTSPlayer.get_move, tests): device arrays [B] */
+int32_t bz_engine_set_roots(bz_engine* e, const uint64_t* own, const uint64_t* opp,
+                            const int8_t* to_move, void* stream);
+/* one full search (root expansion + cfg.sims simulations) for every active slot */
+int32_t bz_engine_search(bz_engine* e, void* stream);
+/* the search, step by step (BZ_EVAL_EXTERNAL callers fill logits/value between) */
+int32_t bz_engine_root_begin(bz_engine* e, void* stream);   /* roots -> leaf buffers       */
+/* sim_index = simulations already completed in this search (0, 1, 2, ...) */
+int32_t bz_engine_select(bz_engine* e, uint32_t sim_index, void* stream); /* M2: PUCT walk + env step */
+int32_t bz_engine_evaluate(bz_engine* e, void* stream);     /* run cfg.eval_kind on leaves */
+int32_t bz_engine_expand_backup(bz_engine* e, void* stream);/* M3 + M4                     */
+/* copy root edge statistics into the root_N/W/P arrays, indexed by action */
+int32_t bz_engine_root_stats(bz_engine* e, void* stream);
+/* M5: pi, move choice, example row, env step, pass rule, terminal handling.
+ * restart != 0: a finished slot starts its next game (next round) at once. */
+int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream);
+/* synchronises the stream; number of active slots / finished games so far */
+int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
+                         int32_t* error_flags);
+int32_t bz_engine_reset_counters(bz_engine* e, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BZ_ABI_H */

@@ -1,0 +1,150 @@
+"""Host-side mirror of the reference's Game API (betazero_amd.ReversiBoard /
+TicTacToeBoard) against fixtures generated from the reference.  CPU only: these
+go through the scalar (host) entry points of libbz_hip.so."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import betazero_amd as bz
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _board(x, o, size):
+    return bz.ReversiBoard.from_bits(x, o, size)
+
+
+def _mask(moves):
+    m = 0
+    for r, c in moves:
+        m |= 1 << (8 * r + c)
+    return m
+
+
+def test_reversi_random_games_fixture_through_the_class():
+    d = np.load(os.path.join(G, "reversi_random_games.npz"))
+    rows = d["rows"].tolist()
+    for gid, size, turn, tm1, x, o, legal, act, flips, over in rows[::3]:
+        cur = int(tm1) - 1
+        b = _board(x, o, size)
+        assert _mask(b.generate_possible_moves(cur)) == legal
+        nb = b
+        if act != 255:
+            nb = b.make_move(act >> 3, act & 7, cur)
+            assert nb.bits(cur)[0] == (b.bits(cur)[0] | flips | 1 << act)
+            assert b.bits(1) == (x, o)  # receiver not mutated (reversi_board.py:47)
+        assert nb.is_game_over() == bool(over)
+    for gid, size, w1, n1, n2, passes, xf, of in d["finals"].tolist():
+        assert _board(xf, of, size).get_score() == (int(w1) - 1, (n1, n2))
+
+
+def test_reversi_arbitrary_positions_fixture():
+    d = np.load(os.path.join(G, "reversi_positions.npz"))
+    pos, moves = d["pos"].tolist(), d["moves"].tolist()
+    for size, x, o, l1, l2, over, w1, n1, n2 in pos:
+        b = _board(x, o, size)
+        assert _mask(b.generate_possible_moves(1)) == l1 and _mask(b.generate_possible_moves(-1)) == l2
+        assert b.is_game_over() == bool(over)
+    for pi, is_x, act, xa, oa in moves[::5]:
+        size, x, o = pos[pi][:3]
+        nb = _board(x, o, size).make_move(act >> 3, act & 7, 1 if is_x else -1)
+        assert nb.bits(1) == (xa, oa)
+
+
+def test_reversi_board_array_is_live_and_copy_ctor():
+    b = bz.ReversiBoard(size=6)
+    assert b.board.dtype == np.int64 and b.board.shape == (6, 6)
+    b.board[0][0] = -1  # edits are picked up, like the reference's plain ndarray attribute
+    assert b.get_score()[1] == (2, 3)
+    c = bz.ReversiBoard(b)
+    assert np.array_equal(c.board, b.board) and c.size == 6
+    c.board[5][5] = 1
+    assert b.board[5][5] == 0
+    with pytest.raises(ValueError):
+        bz.ReversiBoard(size=5)
+
+
+def test_strings_and_demo_sequences():
+    s = json.load(open(os.path.join(G, "strings.json")))
+    for e in s["reversi"]:
+        b = bz.ReversiBoard(size=e["size"])
+        b.board = np.array(e["board"])
+        assert str(b) == e["str"] and repr(b) == e["repr"]
+    b = bz.ReversiBoard(size=4)  # reversi_board.py:92-99
+    for r, c, p in s["reversi_demo"]["moves"]:
+        b = b.make_move(r, c, p)
+    assert b.board.tolist() == s["reversi_demo"]["final"]
+    assert b.is_valid_move(0, 3, -1) == s["reversi_demo"]["valid_0_3_minus1"]
+    for e in s["ttt"]:
+        t = bz.TicTacToeBoard(np.array(e["board"]))
+        assert str(t) == e["str"] and repr(t) == e["repr"]
+    t = bz.TicTacToeBoard().make_move(0, 0, 1).make_move(0, 1, -1).make_move(0, 2, 1)
+    assert t.is_valid_move(0, 0) == s["ttt_demo_valid_0_0"]
+
+
+def test_illegal_moves_raise_valueerror_invalid_move():
+    ill = json.load(open(os.path.join(G, "illegal_moves.json")))
+    for e in ill["reversi"]:
+        b = bz.ReversiBoard(size=e["size"])
+        b.board = np.array(e["board"])
+        with pytest.raises(ValueError, match="^Invalid move$"):
+            b.make_move(e["move"][0], e["move"][1], e["player"])
+        assert not b.is_valid_move(e["move"][0], e["move"][1], e["player"])
+    for e in ill["ttt"]:
+        t = bz.TicTacToeBoard(np.array(e["board"]))
+        with pytest.raises(ValueError, match="^Invalid move$"):
+            t.make_move(e["move"][0], e["move"][1], e["player"])
+
+
+def test_ttt_exhaustive_fixture():
+    d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
+    for x, o, cur, legal, over, w1 in d["pos"].tolist():
+        arr = np.array([[1 if x >> (3 * r + c) & 1 else (-1 if o >> (3 * r + c) & 1 else 0) for c in range(3)]
+                        for r in range(3)])
+        t = bz.TicTacToeBoard(arr)
+        go, w = t.is_game_over()
+        assert go == bool(over) and (2 if w is None else w + 1) == w1
+        m = 0
+        for r, c in t.generate_possible_moves():
+            m |= 1 << (3 * r + c)
+        assert m == legal
+    t = bz.TicTacToeBoard(np.array([[1, 1, 1], [-1, -1, -1], [0, 0, 0]]))
+    assert t.is_game_over() == (True, 1)  # +1 tested first (tic_tac_toe_board.py:32)
+
+
+def test_headless_loop_and_process_game_positions_against_csv():
+    """Replay the reference's CSV games through TicTacToeHeadless with scripted
+    players; process_game_positions must reproduce the CSV rows."""
+    d = np.load(os.path.join(G, "ttt_csv.npz"))
+    st, ac = d["states"], d["actions"]
+
+    class Scripted(bz.Player):
+        def __init__(self, moves):
+            self.moves = list(moves)
+
+        def get_move(self, board):
+            return self.moves.pop(0)
+
+    for g in range(20):
+        mv = [divmod(int(np.argmax(ac[9 * g + k])), 3) for k in range(9)]
+        game = bz.TicTacToeHeadless(Scripted(mv[0::2]), Scripted(mv[1::2]))
+        positions, winner = game.play()
+        assert winner == 0 and len(positions) == 10  # minimax self-play always draws in 9
+        states, actions = bz.process_game_positions(positions)
+        assert np.array_equal(states.reshape(9, 9), st[9 * g:9 * g + 9])
+        assert np.array_equal(actions.reshape(9, 9), ac[9 * g:9 * g + 9])
+    with pytest.raises(ValueError, match="^Invalid move: Invalid move$"):
+        bz.TicTacToeHeadless(Scripted([(0, 0)]), Scripted([(0, 0)])).play()
+
+
+def test_reversi_headless_random_games_terminate_with_pass_rule():
+    import random
+    random.seed(3)
+    for size in (4, 6, 8):
+        g = bz.ReversiHeadless(bz.ReversiRandomPlayer(1), bz.ReversiRandomPlayer(-1), size=size)
+        positions, winner = g.play()
+        assert g.board.is_game_over() and winner in (-1, 0, 1)
+        assert len(positions) == len(g.movers) + 1
+    assert bz.ReversiRandomPlayer(1).get_move(bz.ReversiBoard.from_bits(0, 0, 8)) == (None, None)
