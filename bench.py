@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- self-play games/s on MI355X (BASELINE.json metric).
+
+Default workload = BASELINE config 3: Reversi 8x8, 4096 concurrent games per GPU,
+800 MCTS simulations per move, random-init 6x128 conv policy/value net in bf16
+(MFMA), tau=1 for moves < 8 + 12 fixed two-ply openings.  `--workload ttt` runs
+BASELINE config 2 (65,536 TTT games, 50 sims, uniform priors, tree kernels only).
+
+A "step" (reversi) = one move for every concurrent game: root expansion + 800 x
+(select -> net -> expand/backup) + move choice / example row / env step.  The
+pool runs in steady state: slot g starts pre-advanced by (g % 58) pseudo-random
+plies (untimed setup) and a finished slot immediately starts its next game, so
+every step completes ~B/58 games and value = games completed in the timed
+region / time.  No work is skipped: every move of every game does all 800
+simulations and every non-terminal leaf goes through the full net.
+A "step" (ttt) = one complete iteration: all 65,536 games played to the end.
+
+N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL), games sharded
+by global id (weak scaling: 4096 per GPU), no data-path collective except ONE
+all-gather of the (s, pi, z) buffers at the end of the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TOWER_FLOP_PER_POS = 12 * 2 * 64 * 9 * 128 * 128      # 226.49e6: the 12 conv3x3 layers of k_tower_bf16
+NET_FLOP_PER_POS = 226.86e6                           # stem + tower + heads
+MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+PLIES_PER_GAME = 58                                   # searched moves per cfg-3 game (60 - 2 opening plies)
+
+
+def tree_bytes(c):
+    """SURVEY.md 8(d) algorithmic bytes from the kernels' exact work counters"""
+    return (32 * c["n_path_nodes"] + 12 * c["n_child_scored"] + 16 * c["n_edges_backed"] + 32 * c["n_expanded"] +
+            13 * c["n_child_written"] + 264 * c["n_net_leaves"] + 42 * c["n_env_steps"])
+
+
+def cpu_baseline_reversi(sims, seconds_hint=20):
+    """oracle (CPU restatement, kind "port") on the host cores: `cores` threads x 2 searched
+    moves of cfg-3 games each (bf16-emulating net), extrapolated at 58 searched moves/game"""
+    import numpy as np
+    import torch
+    from betazero_amd.net import PolicyValueNet
+    from oracle import oracle as orc
+    torch.manual_seed(0)
+    mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
+    net = orc.Net(128, 6, 64, mod.flat_params())
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    moves = 2
+    done = [0] * cores
+
+    def work(i):
+        r = orc.selfplay_game(orc.GAME_REVERSI, i, sims, orc.EVAL_NET_BF16, 8, 1, 0, net=net, max_moves=moves)
+        done[i] = len(r["own"])
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.time() - t0
+    return {"value": sum(done) / dt / PLIES_PER_GAME, "unit": "games/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {moves} searched moves ({sims} sims, {sims + 1} net evals per move) of "
+                      f"cfg-3 games in {dt:.1f} s; extrapolated at {PLIES_PER_GAME} searched moves per game"}
+
+
+def cpu_baseline_ttt(sims):
+    from oracle import oracle as orc
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    per = 4000
+    t0 = time.time()
+
+    def work(i):
+        for g in range(per):
+            orc.selfplay_game(orc.GAME_TTT, g, sims, orc.EVAL_UNIFORM)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.time() - t0
+    return {"value": cores * per / dt, "unit": "games/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {per} complete TTT games ({sims} sims/move, uniform priors) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt"])
+    ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
+    ap.add_argument("--sims", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    n_gpus = world
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+
+    from betazero_amd import _lib
+    from betazero_amd.distributed import all_gather_example_tensors
+    from betazero_amd.engine import SelfPlayEngine
+    from betazero_amd.net import DeviceNet, PolicyValueNet
+    _lib.require_gpu()
+    L = _lib.lib()
+
+    reversi = args.workload == "reversi"
+    B = args.games or (4096 if reversi else 65536)
+    sims = args.sims or (800 if reversi else 50)
+    K = args.steps if args.steps is not None else (8 if reversi else 20)
+    W = args.warmup if args.warmup is not None else (1 if reversi else 2)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if reversi:
+        torch.manual_seed(0)
+        mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
+        net = DeviceNet.from_module(mod, B, dev)
+        rounds = 2 + (W + K) // 40
+        eng = SelfPlayEngine("reversi", B, sims, "net_bf16", net, temp_moves=8, openings=1, seed=0, rounds=rounds,
+                             game_id_base=rank * B, game_id_stride=world * B, device=dev, stagger=PLIES_PER_GAME)
+        eng.reset_games()
+
+        def step():
+            eng.search()
+            eng.play(True)
+    else:
+        eng = SelfPlayEngine("ttt", B, sims, "uniform", game_id_base=rank * B, game_id_stride=world * B, device=dev)
+
+        def step():
+            eng.reset_games()
+            for _ in range(9):  # a TTT game has at most 9 moves; finished slots idle
+                eng.search()
+                eng.play(False)
+
+    for _ in range(W):
+        step()
+    _, fin0 = eng.status()
+    eng.reset_counters()
+    L.bz_profile_reset()
+    L.bz_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    if world > 1:  # the one exchange step: pool this iteration's (s, pi, z)
+        pooled = all_gather_example_tensors(eng.example_tensors())
+        del pooled
+    barrier()
+    dt = time.perf_counter() - t0
+    L.bz_profile_enable(0)
+    _, fin1 = eng.status()
+    if not reversi:
+        fin1, fin0 = K * B, 0
+    games = float(fin1 - fin0)
+    if world > 1:
+        t = torch.tensor([dt, games], dtype=torch.float64, device=dev)
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, games = float(tmax[0]), float(tsum[1])
+    cnt = eng.counters()
+    prof = _lib.profile_read()
+
+    if rank == 0:
+        out = {"metric": "selfplay_games_per_s", "value": games / dt, "unit": "games/s", "n_gpus": n_gpus, "steps": K,
+               "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "data": "synthetic"}
+        if reversi:
+            out["dtype"] = "bf16"
+            out["config"] = {"workload": "reversi8x8_4096games_800sims_convnet6x128_bf16" if (B, sims) == (4096, 800)
+                             else f"reversi8x8_{B}games_{sims}sims_convnet6x128_bf16",
+                             "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8,
+                             "openings": 12, "net": "stem + 6 residual blocks x 128 ch, random init seed 0",
+                             "step": "one move for all concurrent games (steady-state pool, staggered starts)",
+                             "parallelism": f"games sharded over {n_gpus} GPU(s), one all-gather of examples"}
+            launches, timed, ms = prof["tower"]
+            avg_ms = ms / max(timed, 1)
+            ach = B * TOWER_FLOP_PER_POS / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_tower_bf16", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches": launches, "avg_launch_ms": avg_ms,
+                               "flop_per_launch": B * TOWER_FLOP_PER_POS}
+            tb = tree_bytes(cnt)
+            tree_ms = prof["select"][2] * prof["select"][0] / max(prof["select"][1], 1) + \
+                prof["expand_backup"][2] * prof["expand_backup"][0] / max(prof["expand_backup"][1], 1)
+            out["roofline_tree"] = {"bound": "hbm", "kernels": "k_select + k_expand_backup",
+                                    "achieved": tb / (tree_ms * 1e-3) / 1e9 if tree_ms else None,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": tb / (tree_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tree_ms else None,
+                                    "algorithmic_bytes": tb, "kernel_ms": tree_ms}
+            out["sims_per_s"] = cnt["n_sims"] * world / dt
+            out["net_evals_per_s"] = cnt["n_net_leaves"] * world / dt
+            out["net_tflops_e2e"] = cnt["n_net_leaves"] * world * NET_FLOP_PER_POS / dt / 1e12
+            out["kernel_ms_total"] = {k: round(v[2] * v[0] / max(v[1], 1), 3) for k, v in prof.items() if v[0]}
+        else:
+            out["dtype"] = "u64+f32"
+            out["config"] = {"workload": "ttt3x3_65536games_50sims_uniform_tree_only" if (B, sims) == (65536, 50)
+                             else f"ttt3x3_{B}games_{sims}sims_uniform_tree_only", "games_per_gpu": B,
+                             "sims_per_move": sims, "step": "one complete self-play iteration of all games"}
+            launches, timed, ms = prof["search_fused"]
+            avg_ms = ms / max(timed, 1)
+            tb = tree_bytes(cnt)
+            ach = tb / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_search_fused<TicTacToe>", "achieved": ach,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "launches": launches, "avg_launch_ms": avg_ms,
+                               "algorithmic_bytes_per_launch": tb / max(launches, 1)}
+            out["sims_per_s"] = cnt["n_sims"] * world / dt
+        out["counters"] = cnt
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_reversi(sims) if reversi else cpu_baseline_ttt(sims)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,7 @@ GAME_TTT, GAME_REVERSI = 0, 1
 EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_EXTERNAL = range(5)
 ST_RUNNING, ST_TERMINAL, ST_ILLEGAL, ST_MUST_PASS = range(4)
 PASS_ACTION = 64
+PROF_SLOTS = ("tower", "stem", "heads", "select", "expand_backup", "search_fused", "play", "env_step")
 COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",
                  "n_child_written", "n_env_steps", "n_net_leaves")
 
@@ -19,7 +20,7 @@ u64, u32, i32, i64, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_void_
 
 class EngineCfg(C.Structure):
     _fields_ = [("game", i32), ("n_games", i32), ("sims", i32), ("eval_kind", i32), ("c_puct", C.c_float),
-                ("temp_moves", i32), ("openings", i32), ("rounds", i32), ("t_max", i32), ("reserved", i32),
+                ("temp_moves", i32), ("openings", i32), ("rounds", i32), ("t_max", i32), ("stagger", i32),
                 ("seed", u64), ("game_id_base", u64), ("game_id_stride", u64)]
 
 
@@ -66,6 +67,9 @@ _SIGS = {
     "bz_engine_play": (i32, [vp, i32, vp]),
     "bz_engine_status": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
     "bz_engine_reset_counters": (i32, [vp, vp]),
+    "bz_profile_enable": (i32, [i32]),
+    "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
+    "bz_profile_reset": (i32, []),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 
@@ -79,6 +83,10 @@ def lib():
         if not os.path.exists(SO):
             raise RuntimeError(f"{SO} is missing: build it with `python -m betazero_amd.build` "
                                "(there is no CPU fallback for the HIP engine)")
+        # torch first: its wheel bundles a HIP runtime (libamdhip64.so.7); loading it before
+        # ours makes the dynamic linker bind libbz_hip.so to that same copy (same SONAME), so
+        # the process has ONE HIP runtime and torch tensors / streams are valid in our kernels.
+        import torch  # noqa: F401
         L = C.CDLL(SO)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
@@ -105,3 +113,13 @@ def check(rc):
 def require_gpu():
     if lib().bz_device_count() <= 0:
         raise RuntimeError("betazero_amd: no HIP device visible; the batched engine has no CPU fallback")
+
+
+def profile_read():
+    """{slot: (launches, timed, total_ms)} from the in-library HIP-event timers"""
+    out = {}
+    for i, name in enumerate(PROF_SLOTS):
+        a, b, t = i64(), i64(), C.c_double()
+        check(lib().bz_profile_read(i, C.byref(a), C.byref(b), C.byref(t)))
+        out[name] = (a.value, b.value, t.value)
+    return out

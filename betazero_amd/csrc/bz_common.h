@@ -14,6 +14,14 @@ inline int32_t hip_fail(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return BZ_EHIP;
 }
+// kernel timers (bz_env.hip); no-ops unless bz_profile_enable(1)
+int prof_begin(int slot, hipStream_t s);
+void prof_end(int slot, int idx, hipStream_t s);
+struct ProfScope {
+    int slot, idx; hipStream_t s;
+    ProfScope(int slot_, void* stream) : slot(slot_), s((hipStream_t)stream) { idx = prof_begin(slot, s); }
+    ~ProfScope() { prof_end(slot, idx, s); }
+};
 }  // namespace bz
 
 #define BZ_HIP(call)                                             \

@@ -4,6 +4,8 @@
 // pure 64-bit integer ALU (bz_rules.h) -- HBM-bound at 34+8 B per env step.
 #include <stdarg.h>
 
+#include <vector>
+
 #include "bz_common.h"
 #include "bz_rules.h"
 
@@ -17,7 +19,53 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace bz
 
+namespace bz {
+namespace {
+constexpr int kProfCap = 16384;
+struct ProfSlot { std::vector<hipEvent_t> ev; int64_t launches = 0; int used = 0; };
+ProfSlot g_prof[BZ_PROF_N];
+bool g_prof_on = false;
+}  // namespace
+int prof_begin(int slot, hipStream_t s) {
+    if (!g_prof_on) return -1;
+    ProfSlot& p = g_prof[slot];
+    p.launches++;
+    if (p.used >= kProfCap) return -1;
+    if ((int)p.ev.size() < 2 * (p.used + 1)) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        p.ev.push_back(a); p.ev.push_back(b);
+    }
+    int idx = p.used++;
+    (void)hipEventRecord(p.ev[2 * idx], s);
+    return idx;
+}
+void prof_end(int slot, int idx, hipStream_t s) {
+    if (idx >= 0) (void)hipEventRecord(g_prof[slot].ev[2 * idx + 1], s);
+}
+}  // namespace bz
+
 using namespace bz;
+
+BZ_EXPORT int32_t bz_profile_enable(int32_t on) { bz::g_prof_on = on != 0; return BZ_OK; }
+BZ_EXPORT int32_t bz_profile_reset(void) {
+    (void)hipDeviceSynchronize();
+    for (auto& p : bz::g_prof) { p.launches = 0; p.used = 0; }
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* timed, double* total_ms) {
+    BZ_REQUIRE(slot >= 0 && slot < BZ_PROF_N && launches && timed && total_ms, "bz_profile_read: bad arguments");
+    BZ_HIP(hipDeviceSynchronize());
+    bz::ProfSlot& p = bz::g_prof[slot];
+    double tot = 0;
+    for (int i = 0; i < p.used; ++i) {
+        float ms = 0;
+        BZ_HIP(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+        tot += ms;
+    }
+    *launches = p.launches; *timed = p.used; *total_ms = tot;
+    return BZ_OK;
+}
 
 BZ_EXPORT int32_t bz_abi_version(void) { return BZ_ABI_VERSION; }
 BZ_EXPORT const char* bz_last_error(void) { return bz::g_err; }
@@ -154,6 +202,7 @@ BZ_EXPORT int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp
     BZ_REQUIRE(n >= 0 && own && opp && action && own_next && opp_next && legal_next && status && winner,
                "bz_reversi_step_batch: null pointer");
     if (n == 0) return BZ_OK;
+    ProfScope ps(BZ_PROF_ENV_STEP, stream);
     hipLaunchKernelGGL(k_reversi_step, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, action, n,
                        own_next, opp_next, legal_next, status, winner);
     BZ_LAUNCH_CHECK("k_reversi_step");

@@ -37,7 +37,7 @@ enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_N = 4 };
 enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8 };
 
 struct EngineDev {
-    int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd;
+    int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd, stagger;
     float c_puct;
     u64 seed, id_base, id_stride;
     Node* nodes; Edge* edges;
@@ -219,6 +219,28 @@ __global__ void __launch_bounds__(256) k_reset_games(EngineDev E) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     dev_start_game<G>(E, g, 0);
+    if (E.stagger > 0) {  // bench only: pre-advance by (g % stagger) pseudo-random legal plies
+        u64 own = E.g_own[g], opp = E.g_opp[g];
+        int tm = E.g_to_move[g], made = E.g_moves[g], want = g % E.stagger;
+        bool ok = true;
+        for (int k = 0; k < want && ok; ++k) {
+            u64 lg = G::legal(own, opp);
+            int tv;
+            if (G::terminal(own, opp, tm, lg, &tv)) { ok = false; break; }
+            if (lg == 0) { u64 t = own; own = opp; opp = t; tm = -tm; continue; }
+            int pick = (int)(rng_draw(E.seed ^ 0x5AFEC0DEULL, (u64)g, (u64)k) % (u64)popc64(lg));
+            for (int j = 0; j < pick; ++j) lg &= lg - 1;
+            u64 c0, c1;
+            G::apply(own, opp, ctz64(lg), &c0, &c1);
+            own = c0; opp = c1; tm = -tm; made++;
+        }
+        u64 lg = G::legal(own, opp);
+        int tv;
+        if (ok && !G::terminal(own, opp, tm, lg, &tv)) {
+            if (lg == 0) { u64 t = own; own = opp; opp = t; tm = -tm; }
+            E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm; E.g_moves[g] = made;
+        }
+    }
     for (int r = 0; r < E.rounds; ++r) { E.ex_len[(size_t)r * E.B + g] = -1; E.ex_winner[(size_t)r * E.B + g] = 0; }
     if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; }
 }
@@ -498,6 +520,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
+    d.stagger = cfg->stagger;
     d.c_puct = cfg->c_puct; d.seed = cfg->seed; d.id_base = cfg->game_id_base; d.id_stride = cfg->game_id_stride;
     d.nodes = at<Node>(ws, o.nodes); d.edges = at<Edge>(ws, o.edges);
     d.g_own = at<u64>(ws, o.g_own); d.g_opp = at<u64>(ws, o.g_opp); d.g_to_move = at<int8_t>(ws, o.g_to_move);
@@ -544,7 +567,6 @@ BZ_EXPORT int32_t bz_engine_reset_counters(bz_engine* e, void* stream) {
 
 BZ_EXPORT int32_t bz_engine_reset_games(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
-    BZ_HIP(hipMemsetAsync(e->dev.counters, 0, 16 * 8, (hipStream_t)stream));
     BZ_DISPATCH(e, k_reset_games, stream, e->dev);
     return BZ_OK;
 }
@@ -564,6 +586,7 @@ BZ_EXPORT int32_t bz_engine_root_begin(bz_engine* e, void* stream) {
 }
 
 static int32_t select_step(bz_engine* e, uint32_t sim_idx, void* stream) {
+    ProfScope ps(BZ_PROF_SELECT, stream);
     BZ_DISPATCH(e, k_select, stream, e->dev, sim_idx);
     return BZ_OK;
 }
@@ -591,6 +614,7 @@ BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
 
 BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
+    ProfScope ps(BZ_PROF_EXPAND_BACKUP, stream);
     BZ_DISPATCH(e, k_expand_backup, stream, e->dev);
     return BZ_OK;
 }
@@ -599,6 +623,7 @@ BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     int ek = e->cfg.eval_kind;
     if (ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) {
+        ProfScope ps(BZ_PROF_SEARCH_FUSED, stream);
         BZ_DISPATCH(e, k_search_fused, stream, e->dev, ek);
         return BZ_OK;
     }
@@ -623,6 +648,7 @@ BZ_EXPORT int32_t bz_engine_root_stats(bz_engine* e, void* stream) {
 
 BZ_EXPORT int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream) {
     BZ_REQUIRE(e, "null engine");
+    ProfScope ps(BZ_PROF_PLAY, stream);
     BZ_DISPATCH(e, k_play, stream, e->dev, (int)restart);
     return BZ_OK;
 }

@@ -469,14 +469,19 @@ BZ_EXPORT int32_t bz_net_forward_bf16(bz_net* n, const uint64_t* own, const uint
     BZ_REQUIRE(cnt >= 0 && cnt <= n->max_batch, "bz_net_forward_bf16: batch exceeds max_batch");
     if (cnt == 0) return BZ_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_stem<__bf16>, dim3(cnt), dim3(kTC), 0, s, own, opp, cnt, kTC, n->stem_w, n->stem_b, n->act_h);
+    {
+        ProfScope ps(BZ_PROF_STEM, stream);
+        hipLaunchKernelGGL(k_stem<__bf16>, dim3(cnt), dim3(kTC), 0, s, own, opp, cnt, kTC, n->stem_w, n->stem_b, n->act_h);
+    }
     BZ_LAUNCH_CHECK("k_stem<bf16>");
     if (n->NB > 0) {
+        ProfScope ps(BZ_PROF_TOWER, stream);
         hipLaunchKernelGGL(k_tower_bf16, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256), kTowerLds, s, n->act_h, cnt,
                            2 * n->NB, reinterpret_cast<const uint4*>(n->conv_wf), n->conv_b);
         BZ_LAUNCH_CHECK("k_tower_bf16");
     }
     size_t lds = (64 * (kTC + 1) + 128 + 64 + 64) * sizeof(float);
+    ProfScope ps(BZ_PROF_HEADS, stream);
     hipLaunchKernelGGL(k_heads<__bf16>, dim3(cnt), dim3(192), lds, s, n->act_h, cnt, kTC, n->VH, n->pol_w, n->pol_b,
                        n->polfc_wT, n->polfc_b, n->val_w, n->val_b, n->v1_wT, n->v1_b, n->v2_w, n->v2_b, logits, value);
     BZ_LAUNCH_CHECK("k_heads<bf16>");

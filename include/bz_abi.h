@@ -142,7 +142,8 @@ typedef struct bz_engine_cfg {
     int32_t openings;    /* Reversi: first 2 plies from the 12 fixed openings (game_id % 12) */
     int32_t rounds;      /* example-buffer depth: slot s plays games s, s+stride, ... (>=1) */
     int32_t t_max;       /* example rows per game (64 Reversi, 9 TTT) */
-    int32_t reserved;
+    int32_t stagger;     /* bench only: slot g starts its round-0 game pre-advanced by (g % stagger)
+                          * pseudo-random plies so that completions are spread evenly (0 = off) */
     uint64_t seed;
     uint64_t game_id_base;   /* global id of slot 0, round 0 (= rank * n_games) */
     uint64_t game_id_stride; /* id distance between rounds (= world_size * n_games) */
@@ -194,6 +195,18 @@ int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream);
 int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
                          int32_t* error_flags);
 int32_t bz_engine_reset_counters(bz_engine* e, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* In-library kernel timers: HIP events recorded on the launch stream around  */
+/* each launch of the named kernel (off by default; bench.py turns them on).  */
+/* ------------------------------------------------------------------------ */
+enum { BZ_PROF_TOWER = 0, BZ_PROF_STEM = 1, BZ_PROF_HEADS = 2, BZ_PROF_SELECT = 3, BZ_PROF_EXPAND_BACKUP = 4,
+       BZ_PROF_SEARCH_FUSED = 5, BZ_PROF_PLAY = 6, BZ_PROF_ENV_STEP = 7, BZ_PROF_N = 8 };
+int32_t bz_profile_enable(int32_t on);
+/* synchronises the device; launches = all launches seen, timed = launches that
+ * carried events (capped), total_ms = sum of their durations */
+int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* timed, double* total_ms);
+int32_t bz_profile_reset(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,390 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on the
+same seeded inputs, vs the committed golden fixtures, and size-independent
+properties at BASELINE.json's full sizes.  Integer work bit-exact; tree floats
+(W, P, pi) bit-exact; fp32 net bit-exact; bf16 net within a stated tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from betazero_amd import _lib
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+
+
+def _dev_u64(a):
+    return torch.as_tensor(np.asarray(a, dtype=np.uint64).view(np.int64)).to(DEV)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---------------------------------------------------------------- env step
+def _reversi_step(own, opp, act):
+    n = len(own)
+    o, p, a = _dev_u64(own), _dev_u64(opp), torch.as_tensor(np.asarray(act, dtype=np.uint8)).to(DEV)
+    on, pn, lg = (torch.empty(n, dtype=torch.int64, device=DEV) for _ in range(3))
+    st = torch.empty(n, dtype=torch.uint8, device=DEV)
+    w = torch.empty(n, dtype=torch.int8, device=DEV)
+    _lib.check(_lib.lib().bz_reversi_step_batch(o.data_ptr(), p.data_ptr(), a.data_ptr(), n, on.data_ptr(),
+                                                pn.data_ptr(), lg.data_ptr(), st.data_ptr(), w.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    return (on.cpu().numpy().view(np.uint64), pn.cpu().numpy().view(np.uint64), lg.cpu().numpy().view(np.uint64),
+            st.cpu().numpy(), w.cpu().numpy())
+
+
+def test_reversi_step_batch_on_golden_games():
+    d = np.load(os.path.join(G, "reversi_random_games.npz"))
+    rows = d["rows"][d["rows"][:, 1] == 8]
+    cur = rows[:, 3].astype(np.int64) - 1
+    x, o = rows[:, 4], rows[:, 5]
+    own = np.where(cur == 1, x, o)
+    opp = np.where(cur == 1, o, x)
+    act = np.where(rows[:, 7] == 255, 64, rows[:, 7]).astype(np.uint8)
+    on, pn, lg, st, w = _reversi_step(own, opp, act)
+    # golden: legal mask of the NEXT row of the same game is the legal mask of the next mover
+    for i in range(len(rows)):
+        exp = orc.reversi_apply(int(own[i]), int(opp[i]), 8, int(act[i]) >> 3, int(act[i]) & 7) if act[i] != 64 \
+            else (int(own[i]), int(opp[i]), 0)
+        assert (int(pn[i]), int(on[i])) == (exp[0], exp[1])
+        assert int(lg[i]) == orc.reversi_legal(exp[1], exp[0], 8)
+        over = bool(rows[i, 9])
+        assert (st[i] == _lib.ST_TERMINAL) == over
+        if over:
+            ws, _ = orc.reversi_score(exp[0], exp[1])
+            assert w[i] == ws
+        elif int(lg[i]) == 0:
+            assert st[i] == _lib.ST_MUST_PASS
+        else:
+            assert st[i] == _lib.ST_RUNNING
+    # next-row consistency with the fixture itself
+    same = (rows[1:, 0] == rows[:-1, 0])
+    nxt_legal = rows[1:, 6]
+    assert np.array_equal(lg[:-1][same], nxt_legal[same])
+
+
+def test_reversi_step_batch_arbitrary_positions_and_illegal_actions():
+    d = np.load(os.path.join(G, "reversi_positions.npz"))
+    pos = d["pos"][d["pos"][:, 0] == 8]
+    own, opp, legal = pos[:, 1], pos[:, 2], pos[:, 3]
+    rng = np.random.default_rng(0)
+    act = rng.integers(0, 65, size=len(pos)).astype(np.uint8)
+    on, pn, lg, st, w = _reversi_step(own, opp, act)
+    for i in range(len(pos)):
+        a = int(act[i])
+        ok = (int(legal[i]) == 0) if a == 64 else bool(int(legal[i]) >> a & 1)
+        if not ok:
+            assert st[i] == _lib.ST_ILLEGAL and (int(on[i]), int(pn[i])) == (int(own[i]), int(opp[i]))
+        else:
+            exp = (int(own[i]), int(opp[i]), 0) if a == 64 else orc.reversi_apply(int(own[i]), int(opp[i]), 8, a >> 3, a & 7)
+            assert (int(pn[i]), int(on[i])) == (exp[0], exp[1])
+    # legal_batch == fixture masks
+    o, p = _dev_u64(own), _dev_u64(opp)
+    out = torch.empty(len(pos), dtype=torch.int64, device=DEV)
+    _lib.check(_lib.lib().bz_reversi_legal_batch(o.data_ptr(), p.data_ptr(), len(pos), out.data_ptr(), _stream()))
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), legal)
+
+
+def test_ttt_step_batch_exhaustive():
+    d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
+    pos = np.concatenate([d["pos"], d["extra"]])
+    rows = []
+    for x, o, cur, legal, over, w1 in pos.tolist():
+        tm = 1 if cur == 1 else -1
+        own, opp = (x, o) if tm == 1 else (o, x)
+        for a in range(9):
+            rows.append((own, opp, a, tm))
+    rows = np.array(rows, dtype=np.int64)
+    n = len(rows)
+    t16 = lambda a: torch.as_tensor(a.astype(np.int16)).to(DEV)  # noqa: E731
+    own, opp = t16(rows[:, 0]), t16(rows[:, 1])
+    act = torch.as_tensor(rows[:, 2].astype(np.uint8)).to(DEV)
+    tm = torch.as_tensor(rows[:, 3].astype(np.int8)).to(DEV)
+    on, pn, lg = (torch.empty(n, dtype=torch.int16, device=DEV) for _ in range(3))
+    st = torch.empty(n, dtype=torch.uint8, device=DEV)
+    w = torch.empty(n, dtype=torch.int8, device=DEV)
+    _lib.check(_lib.lib().bz_ttt_step_batch(own.data_ptr(), opp.data_ptr(), act.data_ptr(), tm.data_ptr(), n,
+                                            on.data_ptr(), pn.data_ptr(), lg.data_ptr(), st.data_ptr(), w.data_ptr(),
+                                            _stream()))
+    on, pn, lg, st, w = (t.cpu().numpy() for t in (on, pn, lg, st, w))
+    for i, (o_, p_, a, t) in enumerate(rows.tolist()):
+        if (o_ | p_) >> a & 1:
+            assert st[i] == _lib.ST_ILLEGAL
+            continue
+        me = o_ | 1 << a
+        x, o = (me, p_) if t == 1 else (p_, me)
+        over, win = orc.ttt_game_over(x, o)
+        assert (int(pn[i]), int(on[i])) == (me, p_) and int(lg[i]) == orc.ttt_legal(x, o)
+        assert (st[i] == _lib.ST_TERMINAL) == over and (not over or w[i] == win)
+
+
+# ---------------------------------------------------------------- MCTS search
+def _engine(game, n, sims, ev, **kw):
+    from betazero_amd.engine import SelfPlayEngine
+    return SelfPlayEngine(game, n, sims, ev, **kw)
+
+
+def _cases(kind):
+    return [c for c in json.load(open(os.path.join(G, "mcts_twin.json")))["cases"] if c["kind"] == kind]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "stepwise"])
+def test_search_matches_golden_twin_and_oracle(fused):
+    d = np.load(os.path.join(G, "mcts_twin.npz"))
+    for case in _cases("search"):
+        ev = case["eval"]
+        eng = _engine(case["game"], 3, case["sims"], ev if fused else "external")
+        eng.set_roots([case["own"]] * 3, [case["opp"]] * 3, [case["to_move"]] * 3)
+        if fused:
+            eng.search()
+        else:  # drive the step API with caller-filled logits / value (BZ_EVAL_EXTERNAL)
+            lb = eng.leaf_buffers()
+            na = eng.na
+
+            def fill():
+                torch.cuda.synchronize()
+                own = lb["own"].cpu().numpy().view(np.uint64)
+                opp = lb["opp"].cpu().numpy().view(np.uint64)
+                lg = np.zeros((3, na), np.float32)
+                v = np.zeros(3, np.float32)
+                if ev == "hash":
+                    for g in range(3):
+                        lg[g], v[g] = orc.eval_hash(int(own[g]), int(opp[g]), na)
+                lb["logits"].copy_(torch.from_numpy(lg))
+                lb["value"].copy_(torch.from_numpy(v))
+            eng.root_begin(); fill(); eng.expand_backup()
+            for s in range(case["sims"]):
+                eng.select(s); fill(); eng.expand_backup()
+        N, W, P = eng.root_stats()
+        eng.status()
+        i = case["id"]
+        for g in range(3):
+            assert np.array_equal(N[g], d[f"s{i}_N"]), case
+            assert np.array_equal(W[g].view(np.uint32), d[f"s{i}_W"].view(np.uint32)), case
+            assert np.array_equal(P[g].view(np.uint32), d[f"s{i}_P"].view(np.uint32)), case
+        _, _, _, cnt = orc.mcts_search(orc.GAME_TTT if case["game"] == "ttt" else orc.GAME_REVERSI, case["own"],
+                                       case["opp"], case["to_move"], case["sims"],
+                                       orc.EVAL_UNIFORM if ev == "uniform" else orc.EVAL_HASH)
+        got = eng.counters()
+        for k in ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded", "n_child_written",
+                  "n_env_steps"):
+            assert got[k] == 3 * cnt[k], (k, got, cnt)
+        eng.reset_counters()
+
+
+def test_search_random_reversi_positions_vs_oracle():
+    d = np.load(os.path.join(G, "reversi_random_games.npz"))
+    rows = d["rows"][(d["rows"][:, 1] == 8) & (d["rows"][:, 7] != 255)]
+    rng = np.random.default_rng(5)
+    sel = rows[rng.choice(len(rows), 96, replace=False)]
+    cur = sel[:, 3].astype(np.int64) - 1
+    own = np.where(cur == 1, sel[:, 4], sel[:, 5])
+    opp = np.where(cur == 1, sel[:, 5], sel[:, 4])
+    eng = _engine("reversi", 96, 200, "hash")
+    eng.set_roots(own, opp, cur.astype(np.int8))
+    eng.search()
+    N, W, P = eng.root_stats()
+    eng.status()
+    for g in range(96):
+        n, w, p, _ = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(cur[g]), 200, orc.EVAL_HASH)
+        assert np.array_equal(N[g], n)
+        assert np.array_equal(W[g].view(np.uint32), w.view(np.uint32))
+        assert np.array_equal(P[g].view(np.uint32), p.view(np.uint32))
+
+
+# ---------------------------------------------------------------- self-play
+def _check_selfplay(game, n, sims, ev, temp_moves, openings, seed, base=0, net=None, onet=None):
+    eng = _engine(game, n, sims, ev, net=net, temp_moves=temp_moves, openings=openings, seed=seed, game_id_base=base)
+    eng.run_iteration()
+    ex = eng.examples()
+    winners, lens = eng.winners()
+    ogame = orc.GAME_TTT if game == "ttt" else orc.GAME_REVERSI
+    oev = {"uniform": orc.EVAL_UNIFORM, "hash": orc.EVAL_HASH, "net_f32": orc.EVAL_NET_F32}[ev]
+    for g in range(n):
+        r = orc.selfplay_game(ogame, base + g, sims, oev, temp_moves, openings, seed, net=onet)
+        m = ex.game == base + g
+        assert lens[0, g] == len(r["own"]) and winners[0, g] == r["winner"]
+        assert np.array_equal(ex.own[m], r["own"]) and np.array_equal(ex.opp[m], r["opp"])
+        assert np.array_equal(ex.act[m], r["act"]) and np.array_equal(ex.mover[m], r["mover"])
+        assert np.array_equal(ex.pi[m].view(np.uint32), r["pi"].view(np.uint32))
+        assert np.array_equal(ex.z[m], r["z"])
+    return ex
+
+
+def test_selfplay_ttt_and_reversi_vs_oracle_bitexact():
+    _check_selfplay("ttt", 64, 25, "uniform", 0, 0, 0)          # BASELINE cfg 1 setting
+    _check_selfplay("ttt", 64, 40, "hash", 4, 0, 7, base=100)
+    _check_selfplay("reversi", 48, 24, "hash", 8, 1, 0)          # cfg 3 diversification rules
+    _check_selfplay("reversi", 24, 16, "uniform", 0, 0, 3, base=5)
+
+
+def test_selfplay_matches_golden_twin_fixture():
+    d = np.load(os.path.join(G, "mcts_twin.npz"))
+    for case in _cases("selfplay"):
+        eng = _engine(case["game"], 1, case["sims"], case["eval"], temp_moves=case["temp_moves"],
+                      openings=case["openings"], seed=case["seed"], game_id_base=case["gid"])
+        eng.run_iteration()
+        ex = eng.examples()
+        i = case["id"]
+        assert np.array_equal(ex.own, d[f"g{i}_own"]) and np.array_equal(ex.act, d[f"g{i}_act"])
+        assert np.array_equal(ex.pi.view(np.uint32), d[f"g{i}_pi"].view(np.uint32))
+        assert eng.winners()[0][0, 0] == case["winner"]
+        assert np.array_equal(ex.z, (case["winner"] * d[f"g{i}_mover"]).astype(np.int8))
+
+
+def test_examples_are_canonical_like_the_reference_csv():
+    """s_{k+1} == -(s_k + onehot(a_k)) inside a TTT game (the CSV invariant)."""
+    eng = _engine("ttt", 32, 30, "hash", temp_moves=9, seed=11)
+    eng.run_iteration()
+    ex = eng.examples()
+    s = ex.states().reshape(len(ex), 9).astype(np.int64)
+    for g in np.unique(ex.game):
+        idx = np.nonzero(ex.game == g)[0]
+        for a, b in zip(idx[:-1], idx[1:]):
+            onehot = np.zeros(9, np.int64); onehot[ex.act[a]] = 1
+            assert np.array_equal(s[b], -(s[a] + onehot))
+    assert np.allclose(ex.pi.sum(1), 1.0, atol=1e-6) and set(np.unique(ex.z)) <= {-1, 0, 1}
+
+
+# ---------------------------------------------------------------- net
+def _net(C, NB, seed=0, bf16=False):
+    from betazero_amd.net import PolicyValueNet
+    torch.manual_seed(seed)
+    m = PolicyValueNet(C, NB, 64)
+    if bf16:
+        m.round_to_bf16_()
+    return m
+
+
+def _positions(n, seed=1):
+    d = np.load(os.path.join(G, "reversi_random_games.npz"))
+    rows = d["rows"][d["rows"][:, 1] == 8]
+    idx = np.random.default_rng(seed).choice(len(rows), n, replace=n > len(rows))
+    return rows[idx, 4].copy(), rows[idx, 5].copy()
+
+
+@pytest.mark.parametrize("C,NB", [(32, 2), (64, 1), (128, 6)])
+def test_net_f32_bitexact_vs_oracle(C, NB):
+    from betazero_amd.net import DeviceNet
+    m = _net(C, NB)
+    n = 24 if C == 128 else 64
+    own, opp = _positions(n)
+    dn = DeviceNet.from_module(m, n)
+    lg, v = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=False)
+    on = orc.Net(C, NB, 64, m.flat_params())
+    olg, ov = on.forward(own, opp)
+    assert np.array_equal(lg.cpu().numpy().view(np.uint32), olg.view(np.uint32))
+    assert np.array_equal(v.cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    # and the oracle's net agrees with the plain torch fp32 module (tolerance: summation order)
+    from betazero_amd.net import bits_to_planes
+    with torch.no_grad():
+        tl, tv = m(bits_to_planes(own, opp))
+    assert np.allclose(olg, tl.numpy(), atol=2e-4) and np.allclose(ov, tv.numpy(), atol=2e-5)
+
+
+def test_net_bf16_mfma_vs_oracle_bf16_emulation():
+    """bf16 tower (MFMA, fp32 accumulate) vs the oracle rounding activations to bf16
+    at the same layer boundaries.  Tolerance 2e-2 abs on logits / 1e-2 on value
+    (accumulation order differs; one bf16 ulp is 2^-8 relative)."""
+    from betazero_amd.net import DeviceNet
+    m = _net(128, 6, bf16=True)
+    n = 37  # ragged: not a multiple of the 4-position workgroup tile
+    own, opp = _positions(n, seed=3)
+    dn = DeviceNet.from_module(m, 64)
+    lg, v = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)
+    on = orc.Net(128, 6, 64, m.flat_params())
+    olg, ov = on.forward(own, opp, bf16=True)
+    err_l = np.abs(lg.cpu().numpy() - olg).max()
+    err_v = np.abs(v.cpu().numpy() - ov).max()
+    print("bf16 net max |dlogit|", err_l, "max |dv|", err_v)
+    assert err_l < 2e-2 and err_v < 1e-2
+    flg, fv = on.forward(own, opp, bf16=False)  # report the bf16-vs-fp32 gap too
+    print("bf16-vs-fp32 gap: logits", np.abs(lg.cpu().numpy() - flg).max(), "value", np.abs(v.cpu().numpy() - fv).max())
+
+
+def test_selfplay_with_f32_net_bitexact_vs_oracle():
+    from betazero_amd.net import DeviceNet
+    m = _net(32, 2, seed=4)
+    dn = DeviceNet.from_module(m, 8)
+    on = orc.Net(32, 2, 64, m.flat_params())
+    _check_selfplay("reversi", 8, 12, "net_f32", 8, 1, 0, net=dn, onet=on)
+
+
+def test_selfplay_with_bf16_net_is_legal_and_terminates():
+    from betazero_amd.net import DeviceNet
+    m = _net(128, 6, bf16=True)
+    dn = DeviceNet.from_module(m, 16)
+    eng = _engine("reversi", 16, 8, "net_bf16", net=dn, temp_moves=8, openings=1)
+    eng.run_iteration()
+    ex = eng.examples()
+    winners, lens = eng.winners()
+    assert (lens[0] > 40).all()
+    for g in range(16):  # replay every game through the oracle's rules
+        m_ = ex.game == g
+        own, opp, act = ex.own[m_], ex.opp[m_], ex.act[m_]
+        for k in range(len(own)):
+            assert orc.reversi_legal(int(own[k]), int(opp[k])) >> int(act[k]) & 1
+        r = orc.reversi_apply(int(own[-1]), int(opp[-1]), 8, int(act[-1]) >> 3, int(act[-1]) & 7)
+        assert orc.reversi_game_over(r[0], r[1])
+        x, o = (r[0], r[1]) if ex.mover[m_][-1] == 1 else (r[1], r[0])
+        assert orc.reversi_score(x, o)[0] == winners[0, g]
+
+
+# ---------------------------------------------------------------- players / full size
+def test_mcts_player_plugs_into_the_reference_style_loop():
+    import betazero_amd as bz
+    p1, p2 = bz.MCTSPlayer(1, sims=200, evaluator="uniform"), bz.RandomPlayer()
+    import random
+    random.seed(0)
+    for _ in range(5):
+        positions, winner = bz.TicTacToeHeadless(p1, p2).play()
+        assert winner in (1, 0)  # 200-sim MCTS as X does not lose to a random player
+    g = bz.ReversiHeadless(bz.MCTSPlayer(1, sims=50, evaluator="hash"), bz.ReversiRandomPlayer(-1))
+    positions, winner = g.play()
+    assert g.board.is_game_over()
+    N, _, _, _ = orc.mcts_search(orc.GAME_REVERSI, *bz.ReversiBoard().bits(1), 1, 50, orc.EVAL_HASH)
+    pl = bz.MCTSPlayer(1, sims=50, evaluator="hash")
+    assert pl.get_move(bz.ReversiBoard()) == divmod(int(np.argmax(N)), 8)
+    assert np.array_equal(pl.last_visits, N)
+
+
+def test_cfg2_full_size_ttt_properties():
+    """BASELINE cfg 2 at full size: 65,536 concurrent TTT games, 50 sims, uniform
+    priors.  All games are identical by construction, so one oracle game pins
+    all of them; plus checksum-style invariants."""
+    eng = _engine("ttt", 65536, 50, "uniform")
+    eng.run_iteration()
+    ex = eng.examples()
+    r = orc.selfplay_game(orc.GAME_TTT, 0, 50, orc.EVAL_UNIFORM)
+    winners, lens = eng.winners()
+    assert (lens[0] == len(r["own"])).all() and (winners[0] == r["winner"]).all()
+    T = len(r["own"])
+    assert np.array_equal(ex.own.reshape(65536, T), np.broadcast_to(r["own"], (65536, T)))
+    assert np.array_equal(ex.pi.reshape(65536, T, 9).view(np.uint32),
+                          np.broadcast_to(r["pi"].view(np.uint32), (65536, T, 9)))
+    cnt = eng.counters()
+    assert cnt["n_sims"] == 65536 * 50 * T and cnt["n_edges_backed"] > cnt["n_sims"]
+
+
+def test_cfg3_size_reversi_batch_properties():
+    """4096 concurrent Reversi games (cfg 3 batch, hash evaluator, 32 sims):
+    per-game oracle spot checks + invariants over the whole batch."""
+    eng = _engine("reversi", 4096, 32, "hash", temp_moves=8, openings=1)
+    eng.run_iteration()
+    ex = eng.examples()
+    winners, lens = eng.winners()
+    assert (lens[0] >= 7).all() and (lens[0] <= 58).all()  # 9 plies is the shortest Reversi game (2 are openings)
+    assert np.allclose(ex.pi.sum(1), 1.0, atol=1e-6)
+    assert np.array_equal(ex.z, (winners[0][ex.game] * ex.mover).astype(np.int8))
+    assert (ex.own & ex.opp == 0).all()
+    for g in (0, 1, 777, 4095):
+        r = orc.selfplay_game(orc.GAME_REVERSI, g, 32, orc.EVAL_HASH, 8, 1, 0)
+        m = ex.game == g
+        assert np.array_equal(ex.act[m], r["act"]) and np.array_equal(ex.pi[m].view(np.uint32), r["pi"].view(np.uint32))
+    assert len(set(ex.act[ex.ply == 0].tolist())) > 1  # openings + tau=1 diversify the games
