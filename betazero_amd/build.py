@@ -28,7 +28,7 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return SO
-    cmd = [hipcc()] + FLAGS + ["-o", SO] + SRC
+    cmd = [hipcc()] + FLAGS + os.environ.get("BZ_EXTRA_HIPCC_FLAGS", "").split() + ["-o", SO] + SRC
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

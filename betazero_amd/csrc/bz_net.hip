@@ -40,6 +40,7 @@ struct bz_net {
     float *stem_w, *stem_b;          // [9][2][C], [C]
     float *conv_w, *conv_b;          // [2NB][9][C][C] as [tap][ci][co]; [2NB][C]
     __bf16* conv_wf;                 // [2NB+pad][9][8][4][64][8] fragment-major (C == 128)
+    __bf16 *stem_wf, *head_wf;       // [2][4][64][8], [8][64][8] fragments (C == 128)
     float *pol_w, *pol_b, *polfc_wT, *polfc_b;  // [2][C], [2], [128][65], [65]
     float *val_w, *val_b, *v1_wT, *v1_b, *v2_w, *v2_b;  // [C], [1], [64][VH], [VH], [VH], [1]
     // activations (device)
@@ -172,131 +173,327 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
 
 // ------------------------------------------------------------------ bf16 MFMA tower
 constexpr int kTC = 128;                  // channels
-constexpr int kPosPerWG = 4;
 constexpr int kTileBytes = 65 * 256;      // 64 cells x 256 B + one zero cell
-constexpr int kBufBytes = kPosPerWG * kTileBytes;
-constexpr int kTowerLds = 2 * kBufBytes;  // 133,120 B
+#ifndef BZ_TOWER_P
+#define BZ_TOWER_P 4
+#endif
+constexpr int kPosPerWG = BZ_TOWER_P;    // positions resident per workgroup (4: one WG per CU; 2: two WGs per CU)
+template <int P> constexpr int buf_bytes() { return P * kTileBytes; }
+template <int P> constexpr int tower_lds() { return 2 * P * kTileBytes; }
 constexpr int kFragsPerLayer = 9 * 8 * 4 * 64;  // 16-byte fragments per layer
 
+#ifdef BZ_EXP_STAMPS
+__device__ unsigned long long g_dbg[8 * 4096];
+#define BZ_STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
+#else
+#define BZ_STAMP(var) do { } while (0)
+#endif
 // byte offset of 16-byte chunk k of cell c inside a position tile (XOR swizzle:
 // the 16 lanes of every ds_read_b128 lane group hit 16 distinct slots)
 __device__ __forceinline__ int cell_off(int c, int k) { return c * 256 + ((k ^ (c & 15)) << 4); }
 
-__global__ void __launch_bounds__(256, 1)
-k_tower_bf16(__bf16* __restrict__ act, int n, int n_layers, const uint4* __restrict__ wf,
-             const float* __restrict__ bias) {
+__device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int cell = 32 * nt + r, yy = (cell >> 3) + dy, xx = (cell & 7) + dx;
+        bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
+        int c2 = inb ? yy * 8 + xx : 64;  // out of the board -> the zero cell
+        // swizzle from the UNCLAMPED coordinates: a halo lane then reads the slot of the zero
+        // cell that its virtual cell would occupy, so the 16 lanes of a ds_read_b128 group
+        // still hit 16 distinct slots (no bank conflict between halo and board lanes)
+        int sw = (xx & 7) | ((yy & 1) << 3);
+        boff[nt] = c2 * 256 + ((sw ^ h) << 4);
+    }
+}
+template <int P>
+__device__ __forceinline__ void load_b(bf16x8 (&b)[P][2], const char* in, const int (&boff)[2], int kc) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const char* bp = in + (boff[nt] ^ (kc << 5));
+#pragma unroll
+#ifdef BZ_EXP_NO_BLOAD
+        for (int p = 0; p < P; ++p) { asm volatile("" : "+v"(b[p][nt]) : "v"(bp)); }
+#else
+        for (int p = 0; p < P; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * kTileBytes);
+#endif
+    }
+}
+template <int P>
+__device__ __forceinline__ void mfma8(f32x16 (&acc)[P][2], const bf16x8& a, const bf16x8 (&b)[P][2]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#ifdef BZ_EXP_NO_MFMA
+            { asm volatile("" :: "v"(a), "v"(b[p][nt])); }
+#else
+            acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[p][nt], acc[p][nt], 0, 0, 0);
+#endif
+}
+
+// One conv tap = 8 k-steps of 8 MFMAs.  Weight fragments of this tap are in register
+// set S (A0 or A1); the other set is filled for the next tap (one coalesced 1 KB load per
+// k-step, a whole tap ahead).  Activation fragments are double-buffered (b0/b1): the 8
+// ds_read_b128 of k-step k+1 are issued between the MFMAs of k-step k.
+template <int S, int P>
+__device__ __forceinline__ void tap_step(f32x16 (&acc)[P][2], bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap,
+                                         const char* in, int (&boff)[2], int next_tap, int r, int h,
+                                         bf16x8 (&b0)[P][2], bf16x8 (&b1)[P][2]) {
+    bf16x8 (&use)[8] = S ? A1 : A0;
+    bf16x8 (&nxt)[8] = S ? A0 : A1;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) nxt[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
+    ap += 8 * 256;
+    int boff_n[2];
+    tap_off(next_tap, r, h, boff_n);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+        load_b<P>(b1, in, boff, 2 * k2 + 1);
+        mfma8<P>(acc, use[2 * k2], b0);
+        if (k2 < 3) load_b<P>(b0, in, boff, 2 * k2 + 2);
+        else load_b<P>(b0, in, boff_n, 0);  // first k-step of the next tap
+        mfma8<P>(acc, use[2 * k2 + 1], b1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2 * P; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
+    }
+    boff[0] = boff_n[0]; boff[1] = boff_n[1];
+}
+
+// +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]: lane (r, h) register 4q+i
+// holds co = 32w + 8q + 4h + i of cell 32nt + r, i.e. 4 consecutive channels = one 8-byte store.
+template <int P>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[P][2], char* out, bool second, const float* __restrict__ bl,
+                                         int w, int r, int h) {
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q);
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int cell = 32 * nt + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int off = p * kTileBytes + cell_off(cell, 4 * w + q) + 8 * h;
+                f32x4 v = {acc[p][nt][4 * q], acc[p][nt][4 * q + 1], acc[p][nt][4 * q + 2], acc[p][nt][4 * q + 3]};
+                v = v + bq[q];
+                if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
+                    bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+                    v = v + __builtin_convertvector(sk, f32x4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
+            }
+        }
+}
+
+// One conv3x3 layer over the 4 resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
+// S0 = register set that holds tap 0's weight fragments on entry (the other one on exit).
+template <int S0, int P>
+__device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
+                                           bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap, int w, int r, int h,
+                                           unsigned long long (&tacc)[4]) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    BZ_STAMP(t0);
+    f32x16 acc[P][2];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { acc[p][0] = (f32x16)(0.0f); acc[p][1] = (f32x16)(0.0f); }
+    int boff[2];
+    tap_off(0, r, h, boff);
+    bf16x8 b0[P][2], b1[P][2];
+    load_b<P>(b0, in, boff, 0);
+    if (S0 == 0) {
+#pragma unroll 1
+        for (int t = 0; t < 8; t += 2) {
+            tap_step<0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
+            tap_step<1, P>(acc, A0, A1, ap, in, boff, t + 2, r, h, b0, b1);
+        }
+        tap_step<0, P>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
+    } else {
+        tap_step<1, P>(acc, A0, A1, ap, in, boff, 1, r, h, b0, b1);
+#pragma unroll 1
+        for (int t = 1; t < 9; t += 2) {
+            tap_step<0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
+            tap_step<1, P>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
+        }
+    }
+    BZ_STAMP(t1);
+#ifdef BZ_EXP_NO_EPI
+    if (acc[0][0][0] == 12345.678f) out[0] = 1;  // keep acc live
+    __syncthreads();
+    return;
+#endif
+    epilogue<P>(acc, out, second, bl, w, r, h);
+    BZ_STAMP(t2);
+    __syncthreads();
+    BZ_STAMP(t3);
+    tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
+}
+
+struct TowerArgs {
+    const u64 *own, *opp;            // [n] bitboards, side-to-move canonical
+    int n, n_layers, VH;
+    const uint4* wf;                 // tower weight fragments (see bz_net_create)
+    const float* bias;               // [n_layers][128]
+    const uint4* stem_wf;            // [2][4][64] fragments of the stem as a K=32 GEMM (k = 2*tap + plane)
+    const float* stem_b;             // [128]
+    const uint4* head_wf;            // [8][64] fragments: rows 0,1 = policy conv1x1, row 2 = value conv1x1
+    const float *pol_b, *val_b;      // [2], [1]
+    const float *polfc_wT, *polfc_b; // [128][65], [65]
+    const float *v1_wT, *v1_b, *v2_w, *v2_b;  // [64][VH], [VH], [VH], [1]
+    float *logits, *value;           // [n][65], [n]
+};
+
+// stem input fragment: B[k][cell] with k = 2*tap + plane (k < 18), built from the bitboards
+__device__ __forceinline__ bf16x8 stem_frag(u64 own, u64 opp, int cell, int kbase) {
+    const int y = cell >> 3, x = cell & 7;
+    unsigned wd[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int k = kbase + j, tap = k >> 1;
+        int t3 = (tap * 11) >> 5;  // tap / 3 for tap < 16
+        int yy = y + t3 - 1, xx = x + (tap - 3 * t3) - 1;
+        bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u && k < 18;
+        u64 brd = (j & 1) ? opp : own;  // kbase is even: plane = j & 1
+        unsigned bit = inb ? (unsigned)((brd >> ((yy * 8 + xx) & 63)) & 1ULL) : 0u;
+        wd[j >> 1] |= bit ? (0x3F80u << (16 * (j & 1))) : 0u;  // bf16 1.0
+    }
+    uint4 u = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// The whole net forward for P positions per workgroup: stem (MFMA, K = 18 padded to 32, fed from
+// the bitboards) -> residual tower (activations resident in LDS) -> heads (conv1x1 by MFMA, the
+// small FCs by one wave per position).  HBM traffic per position: 16 B in, 264 B out.
+template <int P>
+__global__ void __launch_bounds__(256, 4 / P)
+k_tower_bf16(TowerArgs T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos0 = blockIdx.x * kPosPerWG;
+    const int pos0 = blockIdx.x * P;
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tr0 = 0, tr1 = 0;
+    BZ_STAMP(tk0);
+#ifdef BZ_EXP_STAMPS
+    tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     char* bufX = smem;
-    char* bufM = smem + kBufBytes;
+    char* bufM = smem + buf_bytes<P>();
+    const int r = lane & 31, h = lane >> 5;
 
-    // ---- zero cells, then the 4 input tiles (coalesced 16-B chunks, swizzled LDS image)
-    if (tid < 128) {
-        int b = tid >> 6, p = (tid >> 4) & 3, k = tid & 15;
-        *reinterpret_cast<uint4*>(smem + b * kBufBytes + p * kTileBytes + 64 * 256 + k * 16) = make_uint4(0, 0, 0, 0);
+    // ---- zero cells (conv halo) of both buffers
+    if (tid < 32 * P) {
+        int b = tid / (16 * P), p = (tid >> 4) % P, k = tid & 15;
+        *reinterpret_cast<uint4*>(smem + b * buf_bytes<P>() + p * kTileBytes + 64 * 256 + k * 16) = make_uint4(0, 0, 0, 0);
     }
+    // weight-fragment stream of this wave: k-step ks -> wf[(ks*4 + w)*64 + lane], linear over layers
+    const uint4* ap = T.wf + (size_t)w * 64 + lane;
+    bf16x8 A0[8], A1[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) A0[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
+    ap += 8 * 256;
+
+    // ---- stem: conv3x3 2 -> 128 as a [128 x 32] x [32 x 64] GEMM per position
     {
-        const uint4* src = reinterpret_cast<const uint4*>(act) + (size_t)pos0 * 1024;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            int i = it * 256 + tid, p = i >> 10, c = (i >> 4) & 63, k = i & 15;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (pos0 + p < n) v = src[i];
-            *reinterpret_cast<uint4*>(bufX + p * kTileBytes + cell_off(c, k)) = v;
+        f32x16 acc[P][2];
+        bf16x8 sa[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) sa[kc] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + w) * 64 + lane]);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int pos = pos0 + p < T.n ? pos0 + p : T.n - 1;
+            u64 own = T.own[pos], opp = T.opp[pos];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[p][nt] = (f32x16)(0.0f);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc], stem_frag(own, opp, 32 * nt + r, 16 * kc + 8 * h),
+                                                                        acc[p][nt], 0, 0, 0);
+            }
         }
+        epilogue<P>(acc, bufX, false, T.stem_b, w, r, h);
     }
     __syncthreads();
 
-    const int r = lane & 31, h = lane >> 5;
-    // weight-fragment stream of this wave: k-step ks -> wf[(ks*4 + w)*64 + lane], linear over layers
-    const uint4* ap = wf + (size_t)w * 64 + lane;
-    bf16x8 a_cur[8], a_nxt[8];
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) a_cur[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
-    ap += 8 * 256;
+    // ---- tower: a residual block = conv1 (X -> M) + conv2 (M -> X in place, + skip X)
+#pragma unroll 1
+    for (int blk = 0; blk < T.n_layers / 2; ++blk) {
+        conv_layer<0, P>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h, tacc);
+        conv_layer<1, P>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w, r, h, tacc);
+    }
+    BZ_STAMP(tk1);
 
-    for (int layer = 0; layer < n_layers; ++layer) {
-        const bool second = layer & 1;  // conv2 of a block: in = M, out = X (in place), skip = X
-        const char* in = second ? bufM : bufX;
-        char* out = second ? bufX : bufM;
-        f32x16 acc[kPosPerWG][2];
+    // ---- heads: wave p serves position p.  conv1x1 (policy 2 ch + value 1 ch) by MFMA against
+    // the resident tile, then the FCs in fp32 with the position's 192 features staged in LDS.
+    if (w < P && pos0 + w < T.n) {
+        const int p = w, pos = pos0 + w;
+        float* S = reinterpret_cast<float*>(bufM + p * 1024);  // [pf 128 | vf 64]
+        const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
 #pragma unroll
-        for (int p = 0; p < kPosPerWG; ++p) { acc[p][0] = (f32x16)(0.0f); acc[p][1] = (f32x16)(0.0f); }
-
-        for (int tap = 0; tap < 9; ++tap) {
-            // next tap's (or next layer's first tap's) weight fragments; the buffer is padded by one tap
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) a_nxt[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
-            ap += 8 * 256;
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            int boff[2];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                int cell = 32 * nt + r, yy = (cell >> 3) + dy, xx = (cell & 7) + dx;
-                bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
-                int c2 = inb ? yy * 8 + xx : 64;
-                boff[nt] = c2 * 256 + (((c2 & 15) ^ h) << 4);
-            }
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc = (f32x16)(0.0f);
+            const int cell = 32 * nt + r;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
-                bf16x8 bfr[kPosPerWG][2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const char* bp = in + (boff[nt] ^ (kc << 5));
-#pragma unroll
-                    for (int p = 0; p < kPosPerWG; ++p)
-                        bfr[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * kTileBytes);
-                }
-#pragma unroll
-                for (int p = 0; p < kPosPerWG; ++p)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur[kc], bfr[p][nt], acc[p][nt], 0, 0, 0);
+                bf16x8 a = __builtin_bit_cast(bf16x8, T.head_wf[kc * 64 + lane]);
+                bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * kTileBytes + cell_off(cell, 2 * kc + h));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) a_cur[kc] = a_nxt[kc];
+            if (h == 0) {  // rows 0..2 of D live in registers 0..2 of lanes 0..31
+                float a0 = acc[0] + pb0, a1 = acc[1] + pb1, a2 = acc[2] + vb;
+                S[cell] = a0 > 0.0f ? a0 : 0.0f;
+                S[64 + cell] = a1 > 0.0f ? a1 : 0.0f;
+                S[128 + cell] = a2 > 0.0f ? a2 : 0.0f;
+            }
         }
-
-        // ---- epilogue: +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]:
-        // lane (r, h) register 4q+i holds co = 32w + 8q + 4h + i of cell 32nt + r.
-        f32x4 bq[4];
-        const float* bl = bias + (size_t)layer * kTC + 32 * w + 4 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 8 * q);
-#pragma unroll
-        for (int p = 0; p < kPosPerWG; ++p)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                int cell = 32 * nt + r;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int off = p * kTileBytes + cell_off(cell, 4 * w + q) + 8 * h;
-                    f32x4 v = {acc[p][nt][4 * q], acc[p][nt][4 * q + 1], acc[p][nt][4 * q + 2], acc[p][nt][4 * q + 3]};
-                    v = v + bq[q];
-                    if (second) {
-                        bf16x4 s = *reinterpret_cast<const bf16x4*>(out + off);
-                        v = v + __builtin_convertvector(s, f32x4);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-                    *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
-                }
-            }
-        __syncthreads();
-    }
-
-    // ---- result tile (always X after an even number of layers) back to HBM
-    {
-        uint4* dst = reinterpret_cast<uint4*>(act) + (size_t)pos0 * 1024;
-        const char* res = (n_layers & 1) ? bufM : bufX;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes have landed
+        // policy FC 128 -> 65: lane a owns logit a; logit 64 (pass) is a wave reduction
+        float acc = T.polfc_b[lane], part = 0.0f;
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            int i = it * 256 + tid, p = i >> 10, c = (i >> 4) & 63, k = i & 15;
-            if (pos0 + p < n) dst[i] = *reinterpret_cast<const uint4*>(res + p * kTileBytes + cell_off(c, k));
+        for (int i = 0; i < 128; i += 4) {
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(S + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(s4[j], T.polfc_wT[(i + j) * 65 + lane], acc);
         }
+        part = S[lane] * T.polfc_wT[lane * 65 + 64] + S[lane + 64] * T.polfc_wT[(lane + 64) * 65 + 64];
+        part = wave_sum(part);
+        T.logits[(size_t)pos * 65 + lane] = acc;
+        if (lane == 0) T.logits[(size_t)pos * 65 + 64] = part + T.polfc_b[64];
+        // value FC 64 -> VH -> 1, tanh
+        float vh = 0.0f;
+        if (lane < T.VH) {
+            float a = T.v1_b[lane];
+#pragma unroll 4
+            for (int i = 0; i < 64; ++i) a = __builtin_fmaf(S[128 + i], T.v1_wT[i * T.VH + lane], a);
+            vh = (a > 0.0f ? a : 0.0f) * T.v2_w[lane];
+        }
+        vh = wave_sum(vh);
+        if (lane == 0) T.value[pos] = tanhf_spec(vh + T.v2_b[0]);
     }
+#ifdef BZ_EXP_STAMPS
+    unsigned long long tk2; BZ_STAMP(tk2);
+    tr1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long* d = g_dbg + blockIdx.x * 8;
+        d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tk1 - tk0; d[4] = tk2 - tk0; d[5] = tr1 - tr0; d[6] = tk0; d[7] = tr0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ host helpers
@@ -305,16 +502,17 @@ struct Carver {
     int64_t take(int64_t bytes) { int64_t o = off; off += (bytes + 255) & ~int64_t(255); return o; }
 };
 struct NetOffsets {
-    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
+    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
         v2_b, act_a, act_b, act_h, total;
 };
 NetOffsets net_carve(int C, int NB, int VH, int mb) {
     NetOffsets o{};
     Carver k;
-    int64_t L = 2 * NB, mbp = (mb + 3) & ~3;
+    int64_t L = 2 * NB, mbp = (mb + 7) & ~7;
     o.stem_w = k.take(18LL * C * 4); o.stem_b = k.take(C * 4LL);
     o.conv_w = k.take(L * 9 * C * C * 4); o.conv_b = k.take(L * C * 4);
     o.conv_wf = k.take(C == kTC ? (L * 9 + 1) * 8LL * 4 * 64 * 16 : 0);
+    o.stem_wf = k.take(2 * 4 * 64 * 16); o.head_wf = k.take(8 * 64 * 16);
     o.pol_w = k.take(2LL * C * 4); o.pol_b = k.take(8); o.polfc_wT = k.take(128 * 65 * 4); o.polfc_b = k.take(65 * 4);
     o.val_w = k.take(C * 4LL); o.val_b = k.take(4); o.v1_wT = k.take(64LL * VH * 4); o.v1_b = k.take(VH * 4LL);
     o.v2_w = k.take(VH * 4LL); o.v2_b = k.take(4);
@@ -360,6 +558,7 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->stem_w = at<float>(ws, o.stem_w); n->stem_b = at<float>(ws, o.stem_b);
     n->conv_w = at<float>(ws, o.conv_w); n->conv_b = at<float>(ws, o.conv_b);
     n->conv_wf = C == kTC ? at<__bf16>(ws, o.conv_wf) : nullptr;
+    n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
     n->pol_w = at<float>(ws, o.pol_w); n->pol_b = at<float>(ws, o.pol_b);
     n->polfc_wT = at<float>(ws, o.polfc_wT); n->polfc_b = at<float>(ws, o.polfc_b);
     n->val_w = at<float>(ws, o.val_w); n->val_b = at<float>(ws, o.val_b);
@@ -376,6 +575,17 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     for (int co = 0; co < C; ++co)
         for (int ci = 0; ci < 2; ++ci)
             for (int t = 0; t < 9; ++t) F(o.stem_w)[(t * 2 + ci) * C + co] = q[(co * 2 + ci) * 9 + t];
+    if (C == kTC) {  // stem as GEMM fragments: A[co][k], k = 2*tap + plane, zero for k >= 18
+        uint16_t* sf = reinterpret_cast<uint16_t*>(img.data() + o.stem_wf);
+        for (int kc = 0; kc < 2; ++kc)
+            for (int mt = 0; mt < 4; ++mt)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int j = 0; j < 8; ++j) {
+                        int co = 32 * mt + (ln & 31), k = 16 * kc + 8 * (ln >> 5) + j;
+                        float v = k < 18 ? q[(co * 2 + (k & 1)) * 9 + (k >> 1)] : 0.0f;
+                        sf[(((size_t)kc * 4 + mt) * 64 + ln) * 8 + j] = f2bf(v);
+                    }
+    }
     q += (size_t)C * 18;
     for (int i = 0; i < C; ++i) F(o.stem_b)[i] = q[i];
     q += C;
@@ -416,13 +626,23 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     for (int i = 0; i < VH; ++i) F(o.v2_w)[i] = q[i];
     q += VH;
     F(o.v2_b)[0] = q[0];
+    if (C == kTC) {  // head conv1x1 fragments: rows 0,1 = policy channels, row 2 = value channel
+        uint16_t* hf = reinterpret_cast<uint16_t*>(img.data() + o.head_wf);
+        for (int kc = 0; kc < 8; ++kc)
+            for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 8; ++j) {
+                    int row = ln & 31, k = 16 * kc + 8 * (ln >> 5) + j;
+                    float v = row < 2 ? F(o.pol_w)[row * C + k] : (row == 2 ? F(o.val_w)[k] : 0.0f);
+                    hf[((size_t)kc * 64 + ln) * 8 + j] = f2bf(v);
+                }
+    }
     hipStream_t s = (hipStream_t)stream;
     hipError_t e1 = hipMemcpyAsync(ws, img.data(), (size_t)param_bytes, hipMemcpyHostToDevice, s);
     hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(s) : e1;
     if (e2 != hipSuccess) { delete n; return hip_fail(e2, "bz_net_create upload"); }
     if (C == kTC) {
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTowerLds);
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<kPosPerWG>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
     }
     *out = n;
@@ -430,6 +650,14 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
 }
 
 BZ_EXPORT int32_t bz_net_destroy(bz_net* net) { delete net; return BZ_OK; }
+
+#ifdef BZ_EXP_STAMPS
+BZ_EXPORT int32_t bz_debug_read(void* dst, int64_t bytes) {
+    BZ_HIP(hipDeviceSynchronize());
+    BZ_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dbg), (size_t)bytes));
+    return BZ_OK;
+}
+#endif
 
 static int32_t launch_heads_f32(bz_net* n, int cnt, float* logits, float* value, hipStream_t s) {
     size_t lds = (64 * (n->C + 1) + 128 + 64 + 64) * sizeof(float);
@@ -469,21 +697,18 @@ BZ_EXPORT int32_t bz_net_forward_bf16(bz_net* n, const uint64_t* own, const uint
     BZ_REQUIRE(cnt >= 0 && cnt <= n->max_batch, "bz_net_forward_bf16: batch exceeds max_batch");
     if (cnt == 0) return BZ_OK;
     hipStream_t s = (hipStream_t)stream;
+    TowerArgs T;
+    T.own = own; T.opp = opp; T.n = cnt; T.n_layers = 2 * n->NB; T.VH = n->VH;
+    T.wf = reinterpret_cast<const uint4*>(n->conv_wf); T.bias = n->conv_b;
+    T.stem_wf = reinterpret_cast<const uint4*>(n->stem_wf); T.stem_b = n->stem_b;
+    T.head_wf = reinterpret_cast<const uint4*>(n->head_wf); T.pol_b = n->pol_b; T.val_b = n->val_b;
+    T.polfc_wT = n->polfc_wT; T.polfc_b = n->polfc_b; T.v1_wT = n->v1_wT; T.v1_b = n->v1_b; T.v2_w = n->v2_w;
+    T.v2_b = n->v2_b; T.logits = logits; T.value = value;
     {
-        ProfScope ps(BZ_PROF_STEM, stream);
-        hipLaunchKernelGGL(k_stem<__bf16>, dim3(cnt), dim3(kTC), 0, s, own, opp, cnt, kTC, n->stem_w, n->stem_b, n->act_h);
-    }
-    BZ_LAUNCH_CHECK("k_stem<bf16>");
-    if (n->NB > 0) {
         ProfScope ps(BZ_PROF_TOWER, stream);
-        hipLaunchKernelGGL(k_tower_bf16, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256), kTowerLds, s, n->act_h, cnt,
-                           2 * n->NB, reinterpret_cast<const uint4*>(n->conv_wf), n->conv_b);
-        BZ_LAUNCH_CHECK("k_tower_bf16");
+        hipLaunchKernelGGL(k_tower_bf16<kPosPerWG>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
+                           tower_lds<kPosPerWG>(), s, T);
     }
-    size_t lds = (64 * (kTC + 1) + 128 + 64 + 64) * sizeof(float);
-    ProfScope ps(BZ_PROF_HEADS, stream);
-    hipLaunchKernelGGL(k_heads<__bf16>, dim3(cnt), dim3(192), lds, s, n->act_h, cnt, kTC, n->VH, n->pol_w, n->pol_b,
-                       n->polfc_wT, n->polfc_b, n->val_w, n->val_b, n->v1_wT, n->v1_b, n->v2_w, n->v2_b, logits, value);
-    BZ_LAUNCH_CHECK("k_heads<bf16>");
+    BZ_LAUNCH_CHECK("k_tower_bf16");
     return BZ_OK;
 }

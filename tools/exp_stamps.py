@@ -1,0 +1,25 @@
+import os, sys, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from betazero_amd import _lib
+from betazero_amd.net import DeviceNet, PolicyValueNet
+B = 4096
+rng = np.random.default_rng(0)
+x = rng.integers(0, 2**63, size=B, dtype=np.int64); y = rng.integers(0, 2**63, size=B, dtype=np.int64)
+own = torch.as_tensor(x & ~y).cuda(); opp = torch.as_tensor(y & ~x).cuda()
+torch.manual_seed(0)
+net = DeviceNet.from_module(PolicyValueNet(128, 6, 64).round_to_bf16_(), B)
+for _ in range(20): net.forward(own, opp)
+torch.cuda.synchronize()
+L = C.CDLL(_lib.SO)
+nb = 1024 if os.environ.get("NB_WG") is None else int(os.environ["NB_WG"])
+buf = np.zeros(nb * 8, np.uint64)
+L.bz_debug_read.argtypes = [C.c_void_p, C.c_int64]
+assert L.bz_debug_read(buf.ctypes.data, buf.nbytes) == 0
+d = buf.reshape(nb, 8).astype(np.float64)
+print("per WG (wave 0), cycles:  kloop %.0f  epilogue %.0f  barrier %.0f   layers-total %.0f  kernel-total %.0f" % tuple(d[:, i].mean() for i in (0, 1, 2, 3, 4)))
+clk = d[:, 4] / d[:, 5] * 100e6
+print("in-kernel clock GHz: mean %.3f min %.3f max %.3f" % (clk.mean() / 1e9, clk.min() / 1e9, clk.max() / 1e9))
+print("per layer: kloop %.0f (ideal P=4 %d)  epilogue %.0f  barrier %.0f" % (d[:, 0].mean() / 12, 72 * 8 * 32, d[:, 1].mean() / 12, d[:, 2].mean() / 12))
+t0 = d[:, 7]; print("WG start spread (us): ", np.percentile((t0 - t0.min()) / 100, [0, 25, 50, 75, 100]))
+print("WG duration us: mean %.1f" % (d[:, 5].mean() / 100))
