@@ -192,11 +192,15 @@ def main():
                              "parallelism": f"games sharded over {n_gpus} GPU(s), one all-gather of examples"}
             launches, timed, ms = prof["tower"]
             avg_ms = ms / max(timed, 1)
-            ach = B * TOWER_FLOP_PER_POS / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "k_tower_bf16", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                               "launches": launches, "avg_launch_ms": avg_ms,
-                               "flop_per_launch": B * TOWER_FLOP_PER_POS}
+            # leaves are packed before the net runs: a launch evaluates only the non-terminal leaves
+            pos_per_launch = cnt["n_net_leaves"] / max(launches, 1)
+            flop_per_launch = pos_per_launch * NET_FLOP_PER_POS  # stem + tower + heads are ONE kernel
+            ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "k_tower_bf16 (stem + 12 conv3x3 + heads, fused)",
+                               "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "launches": launches,
+                               "avg_launch_ms": avg_ms, "positions_per_launch": pos_per_launch,
+                               "flop_per_launch": flop_per_launch}
             tb = tree_bytes(cnt)
             tree_ms = prof["select"][2] * prof["select"][0] / max(prof["select"][1], 1) + \
                 prof["expand_backup"][2] * prof["expand_backup"][0] / max(prof["expand_backup"][1], 1)

@@ -24,6 +24,10 @@ struct ProfScope {
 };
 }  // namespace bz
 
+// bz_net.hip: forward over the first *n_dev (device counter, <= max_n) positions; n_dev may be null
+int32_t bz_net_forward_dev(bz_net* net, int bf16, const uint64_t* own, const uint64_t* opp, int32_t max_n,
+                           const uint32_t* n_dev, float* logits, float* value, void* stream);
+
 #define BZ_HIP(call)                                             \
     do {                                                         \
         hipError_t _e = (call);                                  \

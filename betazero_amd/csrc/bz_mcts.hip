@@ -33,17 +33,18 @@ constexpr u32 kTerm = 1u << 8;
 enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2 };
 enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDED, CNT_CHILD_WRITTEN,
        CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_N };
-enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_N = 4 };
+enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_NEVAL = 3, FLAG_N = 4 };
 enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8 };
 
 struct EngineDev {
     int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd, stagger;
+    int compact;  // net evaluators: leaves needing evaluation are packed (c_own/c_opp/logits/value by slot)
     float c_puct;
     u64 seed, id_base, id_stride;
     Node* nodes; Edge* edges;
     u64 *g_own, *g_opp; int8_t* g_to_move; uint8_t* g_state; int32_t *g_moves, *g_nex, *g_round, *g_passes;
     u32 *n_nodes, *n_edges, *path, *depth, *leaf_node;
-    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp;
+    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp, *c_own, *c_opp; u32* leaf_slot;
     float *logits, *value;
     u64 *ex_own, *ex_opp; float* ex_pi; int8_t *ex_z, *ex_mover; uint8_t* ex_act; int32_t* ex_len; int8_t* ex_winner;
     u32* root_N; float *root_W, *root_P;
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(256) k_reset_games(EngineDev E) {
         }
     }
     for (int r = 0; r < E.rounds; ++r) { E.ex_len[(size_t)r * E.B + g] = -1; E.ex_winner[(size_t)r * E.B + g] = 0; }
-    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; }
+    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; }
 }
 
 __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, const u64* opp, const int8_t* tm) {
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, 
     if (g >= E.B) return;
     E.g_own[g] = own[g]; E.g_opp[g] = opp[g]; E.g_to_move[g] = tm[g];
     E.g_state[g] = 0; E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
-    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; }
+    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; }
 }
 
 template <class G>
@@ -264,6 +265,10 @@ __global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
     }
     E.leaf_own[g] = E.g_own[g]; E.leaf_opp[g] = E.g_opp[g];
     E.leaf_kind[g] = kind;
+    if (E.compact && kind == LEAF_EVAL) {
+        u32 slot = atomicAdd(&E.flags[FLAG_NEVAL], 1u);
+        E.leaf_slot[g] = slot; E.c_own[slot] = E.g_own[g]; E.c_opp[slot] = E.g_opp[g];
+    }
 }
 
 template <class G>
@@ -279,6 +284,10 @@ __global__ void __launch_bounds__(256) k_select(EngineDev E, u32 sim_idx) {
             const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
             E.leaf_own[g] = nd->own; E.leaf_opp[g] = nd->opp;
             kind8 = (uint8_t)kind;
+            if (E.compact && kind == LEAF_EVAL) {
+                u32 slot = atomicAdd(&E.flags[FLAG_NEVAL], 1u);
+                E.leaf_slot[g] = slot; E.c_own[slot] = nd->own; E.c_opp[slot] = nd->opp;
+            }
         }
         E.leaf_kind[g] = kind8;
     }
@@ -307,10 +316,11 @@ __global__ void __launch_bounds__(256) k_expand_backup(EngineDev E) {
             float v;
             if (kind == LEAF_EVAL) {
                 u32 ne = E.n_edges[g];
-                LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + (size_t)g * G::NA;
+                size_t row = E.compact ? (size_t)E.leaf_slot[g] : (size_t)g;
+                LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + row * G::NA;
                 dev_expand<G>(E, g, leaf, ls, ne, c);
                 E.n_edges[g] = ne;
-                v = E.value[g];
+                v = E.value[row];
                 c.v[CNT_NET_LEAVES]++;
             } else {
                 u32 info = E.nodes[(size_t)g * E.ncap + leaf].info;
@@ -319,6 +329,7 @@ __global__ void __launch_bounds__(256) k_expand_backup(EngineDev E) {
             dev_backup(E, g, (int)E.depth[g], v, c);
         }
     }
+    if (g == 0) E.flags[FLAG_NEVAL] = 0;  // consumed by the evaluator; the next select packs from 0
     cnt_flush(E, c);
 }
 
@@ -451,7 +462,7 @@ struct Carver {
 
 struct Offsets {
     int64_t nodes, edges, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
-        path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
+        path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
         ex_act, ex_len, ex_winner, root_N, root_W, root_P, counters, flags, total;
     int ncap, ecap, na, maxd;
 };
@@ -478,6 +489,7 @@ Offsets carve(const bz_engine_cfg& c) {
     o.n_nodes = k.take(B * 4); o.n_edges = k.take(B * 4);
     o.path = k.take((int64_t)o.maxd * B * 4); o.depth = k.take(B * 4); o.leaf_node = k.take(B * 4);
     o.leaf_kind = k.take(B); o.leaf_own = k.take(B * 8); o.leaf_opp = k.take(B * 8);
+    o.c_own = k.take(B * 8); o.c_opp = k.take(B * 8); o.leaf_slot = k.take(B * 4);
     o.logits = k.take(B * o.na * 4); o.value = k.take(B * 4);
     o.ex_own = k.take(R * B * T * 8); o.ex_opp = k.take(R * B * T * 8); o.ex_pi = k.take(R * B * T * o.na * 4);
     o.ex_z = k.take(R * B * T); o.ex_mover = k.take(R * B * T); o.ex_act = k.take(R * B * T);
@@ -529,6 +541,8 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.n_nodes = at<u32>(ws, o.n_nodes); d.n_edges = at<u32>(ws, o.n_edges); d.path = at<u32>(ws, o.path);
     d.depth = at<u32>(ws, o.depth); d.leaf_node = at<u32>(ws, o.leaf_node); d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
     d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
+    d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp); d.leaf_slot = at<u32>(ws, o.leaf_slot);
+    d.compact = (cfg->eval_kind == BZ_EVAL_NET_F32 || cfg->eval_kind == BZ_EVAL_NET_BF16) ? 1 : 0;
     d.logits = at<float>(ws, o.logits); d.value = at<float>(ws, o.value);
     d.ex_own = at<u64>(ws, o.ex_own); d.ex_opp = at<u64>(ws, o.ex_opp); d.ex_pi = at<float>(ws, o.ex_pi);
     d.ex_z = at<int8_t>(ws, o.ex_z); d.ex_mover = at<int8_t>(ws, o.ex_mover); d.ex_act = at<uint8_t>(ws, o.ex_act);
@@ -607,9 +621,9 @@ BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
     if (ek == BZ_EVAL_EXTERNAL) return BZ_OK;
     BZ_REQUIRE(e->net, "bz_engine_evaluate: eval_kind needs a net (bz_engine_set_net)");
     BZ_REQUIRE(e->cfg.game == BZ_GAME_REVERSI, "bz_engine_evaluate: the conv net is 8x8 Reversi only");
-    if (ek == BZ_EVAL_NET_F32)
-        return bz_net_forward_f32(e->net, e->dev.leaf_own, e->dev.leaf_opp, e->dev.B, e->dev.logits, e->dev.value, stream);
-    return bz_net_forward_bf16(e->net, e->dev.leaf_own, e->dev.leaf_opp, e->dev.B, e->dev.logits, e->dev.value, stream);
+    // leaves were packed by select: evaluate only the first flags[NEVAL] slots (device-side count)
+    return bz_net_forward_dev(e->net, ek == BZ_EVAL_NET_BF16, e->dev.c_own, e->dev.c_opp, e->dev.B,
+                              e->dev.flags + FLAG_NEVAL, e->dev.logits, e->dev.value, stream);
 }
 
 BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {

@@ -53,9 +53,10 @@ namespace {
 // ------------------------------------------------------------------ stem
 // thread = output channel, block = position.  x in {0,1}: fmaf(1,w,acc) == acc + w.
 template <class OutT>
-__global__ void k_stem(const u64* __restrict__ own, const u64* __restrict__ opp, int n, int C,
+__global__ void k_stem(const u64* __restrict__ own, const u64* __restrict__ opp, int n, const u32* n_dev, int C,
                        const float* __restrict__ w, const float* __restrict__ b, OutT* __restrict__ out) {
     int pos = blockIdx.x, co = threadIdx.x;
+    if (n_dev) n = (int)*n_dev;
     if (pos >= n || co >= C) return;
     u64 me = own[pos], you = opp[pos];
     float wr[18];
@@ -82,10 +83,11 @@ __global__ void k_stem(const u64* __restrict__ own, const u64* __restrict__ opp,
 // block = position, 256 threads; thread = (co, cell group); 8 cells per pass.
 __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ in, const float* __restrict__ w,
                                                   const float* __restrict__ b, const float* skip, float* out, int n,
-                                                  int C) {
+                                                  const u32* n_dev, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);  // [64][C]
     int pos = blockIdx.x;
+    if (n_dev) n = (int)*n_dev;
     if (pos >= n) return;
     const float* xin = in + (size_t)pos * 64 * C;
     for (int i = threadIdx.x; i < 64 * C; i += 256) xs[i] = xin[i];
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(256) k_conv_f32(const float* __restrict__ in, 
 // block = position, 192 threads.  Every dot product is a sequential fmaf chain in
 // the oracle's order, so with f32 activations the result is bit-identical.
 template <class InT>
-__global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int n, int C, int VH,
+__global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int n, const u32* n_dev, int C, int VH,
                                                const float* __restrict__ pol_w, const float* __restrict__ pol_b,
                                                const float* __restrict__ polfc_wT, const float* __restrict__ polfc_b,
                                                const float* __restrict__ val_w, const float* __restrict__ val_b,
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
     float* vf = pf + 128;                            // [64]
     float* vh = vf + 64;                             // [VH]
     int pos = blockIdx.x, tid = threadIdx.x;
+    if (n_dev) n = (int)*n_dev;
     if (pos >= n) return;
     const InT* x = act + (size_t)pos * 64 * C;
     for (int i = tid; i < 64 * C; i += 192) xs[(i / C) * (C + 1) + (i % C)] = (float)x[i];
@@ -341,6 +344,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
 
 struct TowerArgs {
     const u64 *own, *opp;            // [n] bitboards, side-to-move canonical
+    const u32* n_dev;                // optional device-side count (<= n): workgroups beyond it exit at once
     int n, n_layers, VH;
     const uint4* wf;                 // tower weight fragments (see bz_net_create)
     const float* bias;               // [n_layers][128]
@@ -387,6 +391,8 @@ k_tower_bf16(TowerArgs T) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos0 = blockIdx.x * P;
+    if (T.n_dev) T.n = (int)*T.n_dev;
+    if (pos0 >= T.n) return;  // block-uniform, before any barrier
     unsigned long long tacc[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tr0 = 0, tr1 = 0;
     BZ_STAMP(tk0);
 #ifdef BZ_EXP_STAMPS
@@ -659,46 +665,35 @@ BZ_EXPORT int32_t bz_debug_read(void* dst, int64_t bytes) {
 }
 #endif
 
-static int32_t launch_heads_f32(bz_net* n, int cnt, float* logits, float* value, hipStream_t s) {
-    size_t lds = (64 * (n->C + 1) + 128 + 64 + 64) * sizeof(float);
-    hipLaunchKernelGGL(k_heads<float>, dim3(cnt), dim3(192), lds, s, n->act_a, cnt, n->C, n->VH, n->pol_w, n->pol_b,
-                       n->polfc_wT, n->polfc_b, n->val_w, n->val_b, n->v1_wT, n->v1_b, n->v2_w, n->v2_b, logits, value);
-    BZ_LAUNCH_CHECK("k_heads<float>");
-    return BZ_OK;
-}
-
-BZ_EXPORT int32_t bz_net_forward_f32(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, float* logits,
-                                     float* value, void* stream) {
-    BZ_REQUIRE(n && own && opp && logits && value, "bz_net_forward_f32: null pointer");
-    BZ_REQUIRE(cnt >= 0 && cnt <= n->max_batch, "bz_net_forward_f32: batch exceeds max_batch");
-    if (cnt == 0) return BZ_OK;
+static int32_t forward_f32(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, const u32* n_dev,
+                           float* logits, float* value, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int C = n->C;
-    hipLaunchKernelGGL(k_stem<float>, dim3(cnt), dim3(C), 0, s, own, opp, cnt, C, n->stem_w, n->stem_b, n->act_a);
+    hipLaunchKernelGGL(k_stem<float>, dim3(cnt), dim3(C), 0, s, own, opp, cnt, n_dev, C, n->stem_w, n->stem_b, n->act_a);
     BZ_LAUNCH_CHECK("k_stem<float>");
     size_t lds = (size_t)64 * C * sizeof(float);
     for (int blk = 0; blk < n->NB; ++blk) {
         const float* w1 = n->conv_w + (size_t)(2 * blk) * 9 * C * C;
         const float* w2 = n->conv_w + (size_t)(2 * blk + 1) * 9 * C * C;
         hipLaunchKernelGGL(k_conv_f32, dim3(cnt), dim3(256), lds, s, n->act_a, w1, n->conv_b + (size_t)(2 * blk) * C,
-                           (const float*)nullptr, n->act_b, cnt, C);
+                           (const float*)nullptr, n->act_b, cnt, n_dev, C);
         BZ_LAUNCH_CHECK("k_conv_f32");
         hipLaunchKernelGGL(k_conv_f32, dim3(cnt), dim3(256), lds, s, n->act_b, w2,
-                           n->conv_b + (size_t)(2 * blk + 1) * C, (const float*)n->act_a, n->act_a, cnt, C);
+                           n->conv_b + (size_t)(2 * blk + 1) * C, (const float*)n->act_a, n->act_a, cnt, n_dev, C);
         BZ_LAUNCH_CHECK("k_conv_f32");
     }
-    return launch_heads_f32(n, cnt, logits, value, s);
+    size_t hl = (64 * (n->C + 1) + 128 + 64 + 64) * sizeof(float);
+    hipLaunchKernelGGL(k_heads<float>, dim3(cnt), dim3(192), hl, s, n->act_a, cnt, n_dev, n->C, n->VH, n->pol_w, n->pol_b,
+                       n->polfc_wT, n->polfc_b, n->val_w, n->val_b, n->v1_wT, n->v1_b, n->v2_w, n->v2_b, logits, value);
+    BZ_LAUNCH_CHECK("k_heads<float>");
+    return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_net_forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, float* logits,
-                                      float* value, void* stream) {
-    BZ_REQUIRE(n && own && opp && logits && value, "bz_net_forward_bf16: null pointer");
-    BZ_REQUIRE(n->C == kTC, "bz_net_forward_bf16: the MFMA tower is built for C == 128");
-    BZ_REQUIRE(cnt >= 0 && cnt <= n->max_batch, "bz_net_forward_bf16: batch exceeds max_batch");
-    if (cnt == 0) return BZ_OK;
+static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, const u32* n_dev,
+                            float* logits, float* value, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     TowerArgs T;
-    T.own = own; T.opp = opp; T.n = cnt; T.n_layers = 2 * n->NB; T.VH = n->VH;
+    T.own = own; T.opp = opp; T.n_dev = n_dev; T.n = cnt; T.n_layers = 2 * n->NB; T.VH = n->VH;
     T.wf = reinterpret_cast<const uint4*>(n->conv_wf); T.bias = n->conv_b;
     T.stem_wf = reinterpret_cast<const uint4*>(n->stem_wf); T.stem_b = n->stem_b;
     T.head_wf = reinterpret_cast<const uint4*>(n->head_wf); T.pol_b = n->pol_b; T.val_b = n->val_b;
@@ -711,4 +706,23 @@ BZ_EXPORT int32_t bz_net_forward_bf16(bz_net* n, const uint64_t* own, const uint
     }
     BZ_LAUNCH_CHECK("k_tower_bf16");
     return BZ_OK;
+}
+
+int32_t bz_net_forward_dev(bz_net* n, int bf16, const uint64_t* own, const uint64_t* opp, int32_t max_n,
+                           const uint32_t* n_dev, float* logits, float* value, void* stream) {
+    BZ_REQUIRE(n && own && opp && logits && value, "bz_net_forward: null pointer");
+    BZ_REQUIRE(!bf16 || n->C == kTC, "bz_net_forward_bf16: the MFMA tower is built for C == 128");
+    BZ_REQUIRE(max_n >= 0 && max_n <= n->max_batch, "bz_net_forward: batch exceeds max_batch");
+    if (max_n == 0) return BZ_OK;
+    return bf16 ? forward_bf16(n, own, opp, max_n, n_dev, logits, value, stream)
+                : forward_f32(n, own, opp, max_n, n_dev, logits, value, stream);
+}
+
+BZ_EXPORT int32_t bz_net_forward_f32(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, float* logits,
+                                     float* value, void* stream) {
+    return bz_net_forward_dev(n, 0, own, opp, cnt, nullptr, logits, value, stream);
+}
+BZ_EXPORT int32_t bz_net_forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, float* logits,
+                                      float* value, void* stream) {
+    return bz_net_forward_dev(n, 1, own, opp, cnt, nullptr, logits, value, stream);
 }
