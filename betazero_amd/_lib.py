@@ -67,6 +67,7 @@ _SIGS = {
     "bz_engine_play": (i32, [vp, i32, vp]),
     "bz_engine_status": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
     "bz_engine_reset_counters": (i32, [vp, vp]),
+    "bz_engine_sum_counters": (i32, [vp, vp]),
     "bz_profile_enable": (i32, [i32]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
     "bz_profile_reset": (i32, []),

@@ -33,7 +33,9 @@ constexpr u32 kTerm = 1u << 8;
 enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2 };
 enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDED, CNT_CHILD_WRITTEN,
        CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_N };
-enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_NEVAL = 3, FLAG_N = 4 };
+// NEVAL[2]: packed-leaf counters, double-buffered by simulation parity (the tree step that
+// packs into one buffer zeroes the other, so no extra reset launch is needed)
+enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_NEVAL = 4, FLAG_N = 8 };
 enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8 };
 
 struct EngineDev {
@@ -48,18 +50,35 @@ struct EngineDev {
     float *logits, *value;
     u64 *ex_own, *ex_opp; float* ex_pi; int8_t *ex_z, *ex_mover; uint8_t* ex_act; int32_t* ex_len; int8_t* ex_winner;
     u32* root_N; float *root_W, *root_P;
-    u64* counters; u32* flags;
+    u64* counters; u64* cnt_slots; int n_cnt_slots; u32* flags;
 };
 
 struct Cnt { u32 v[CNT_N]; };
 
+// counters are accumulated per wave into that wave's own slot (plain read-modify-write, no
+// atomics: 1000+ waves hammering 8 shared addresses cost more than the tree walk itself);
+// k_sum_counters folds the slots into counters[16] when the host asks.
 __device__ __forceinline__ void cnt_flush(const EngineDev& E, Cnt& c) {
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 #pragma unroll
     for (int k = 0; k < CNT_N; ++k) {
         u32 x = c.v[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd((unsigned long long*)&E.counters[k], (unsigned long long)x);
+        if ((threadIdx.x & 63) == 0 && x && wave < (u32)E.n_cnt_slots) E.cnt_slots[(size_t)wave * CNT_N + k] += x;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sum_counters(EngineDev E) {
+    __shared__ unsigned long long part[256];
+    for (int k = 0; k < CNT_N; ++k) {
+        unsigned long long acc = 0;
+        for (int w = threadIdx.x; w < E.n_cnt_slots; w += 256) acc += E.cnt_slots[(size_t)w * CNT_N + k];
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) E.counters[k] = part[0];
+        __syncthreads();
     }
 }
 
@@ -71,40 +90,62 @@ struct LogitSrc {
     }
 };
 
-// M2: PUCT walk from the root; creates the child node behind the chosen
-// unexpanded edge (env step: apply + legal + terminal).
+// ---- cooperative tree walk: kGW = 16 lanes serve one game (4 games per wave).  A level of the
+// PUCT walk is one broadcast node load + one coalesced 256-byte load of up to 16 edges, the
+// scores are computed one child per lane and reduced with 4 shuffle steps (first maximum, i.e.
+// lowest action on ties); softmax terms are computed one legal move per lane, but SUMMED in
+// ascending action order by a serial shuffle scan so that the result is bit-identical to the
+// sequential spec; the backup updates one path edge per lane.
+constexpr int kGW = 16;
+
+// M2: PUCT walk from the root; creates the child node behind the chosen unexpanded edge (env step:
+// apply + legal + terminal).  All lanes of the group return the same values.
 template <class G>
-__device__ __forceinline__ void dev_select(const EngineDev& E, int g, u32 sim_idx, u32& n_nodes_g, u32& leaf,
-                                           int& kind, int& depth_out, float& tval, Cnt& c) {
+__device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u32 sim_idx, u32& n_nodes_g,
+                                           u32& leaf, int& kind, int& depth_out, float& tval, Cnt& c) {
     Node* nodes = E.nodes + (size_t)g * E.ncap;
     Edge* edges = E.edges + (size_t)g * E.ecap;
     u32 node = 0, sumN = sim_idx;  // sum of the root's child visits == simulations done so far
     int depth = 0;
-    c.v[CNT_SIMS]++;
+    const bool lead = sub == 0;
+    if (lead) c.v[CNT_SIMS]++;
     for (;;) {
         Node nd = nodes[node];
-        c.v[CNT_PATH_NODES]++;
+        if (lead) c.v[CNT_PATH_NODES]++;
         if (nd.info & kTerm) {
             kind = LEAF_TERMINAL; leaf = node; tval = (float)((int)((nd.info >> 9) & 3u) - 1);
             break;
         }
-        int n = (int)(nd.info & 0xFFu);
-        float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
+        const int n = (int)(nd.info & 0xFFu);
+        const float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
         const Edge* ed = edges + nd.edge0;
-        int best = 0; float bests = -__builtin_inff(); u32 bestN = 0, bestca = 0;
-        for (int i = 0; i < n; ++i) {
-            Edge e = ed[i];
-            float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
-            float u = E.c_puct * e.P;
-            u = u * sq;
-            u = fdiv(u, 1.0f + (float)e.N);
-            float s = q + u;
-            if (s > bests) { bests = s; best = i; bestN = e.N; bestca = e.ca; }
+        float bests = -__builtin_inff(); int best = 0; u32 bestN = 0, bestca = 0;
+        for (int base = 0; base < n; base += kGW) {
+            int i = base + sub;
+            float sc = -__builtin_inff(); u32 eN = 0, eca = 0;
+            if (i < n) {
+                Edge e = ed[i];
+                float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
+                float u = E.c_puct * e.P;
+                u = u * sq;
+                u = fdiv(u, 1.0f + (float)e.N);
+                sc = q + u; eN = e.N; eca = e.ca;
+            }
+#pragma unroll
+            for (int o = kGW / 2; o > 0; o >>= 1) {
+                float s2 = __shfl_xor(sc, o, kGW); int i2 = __shfl_xor(i, o, kGW);
+                u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
+                bool take = (s2 > sc) || (s2 == sc && i2 < i);
+                if (take) { sc = s2; i = i2; eN = n2; eca = c2; }
+            }
+            if (sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; }
         }
-        c.v[CNT_CHILD_SCORED] += (u32)n;
+        if (lead) c.v[CNT_CHILD_SCORED] += (u32)n;
         u32 eidx = nd.edge0 + (u32)best;
-        if (depth < E.maxd) E.path[(size_t)depth * E.B + g] = eidx;
-        else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
+        if (lead) {
+            if (depth < E.maxd) E.path[(size_t)depth * E.B + g] = eidx;
+            else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
+        }
         depth++;
         u32 child = bestca & 0xFFFFFFu;
         if (child) {  // children's visits of X == visits of the edge into X minus the creating one
@@ -114,68 +155,92 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, u32 sim_id
         int act = (int)(bestca >> 24);
         u64 cown, copp;
         G::apply(nd.own, nd.opp, act, &cown, &copp);
-        c.v[CNT_ENV_STEPS]++;
         u32 id = n_nodes_g++;
         int tm = ((nd.info >> 11) & 1u) ? -1 : 1;  // child's mover = the other colour
         u64 lg = G::legal(cown, copp);
         int tv = 0;
         bool term = G::terminal(cown, copp, tm, lg, &tv);
-        Node ch;
-        ch.own = cown; ch.opp = copp; ch.legal = term ? 0 : lg; ch.edge0 = 0;
-        ch.info = (term ? kTerm : 0u) | ((u32)(tv + 1) << 9) | ((tm == 1 ? 1u : 0u) << 11);
-        nodes[id] = ch;
-        edges[eidx].ca = id | ((u32)act << 24);
-        c.v[CNT_PATH_NODES]++;
+        if (lead) {
+            Node ch;
+            ch.own = cown; ch.opp = copp; ch.legal = term ? 0 : lg; ch.edge0 = 0;
+            ch.info = (term ? kTerm : 0u) | ((u32)(tv + 1) << 9) | ((tm == 1 ? 1u : 0u) << 11);
+            nodes[id] = ch;
+            edges[eidx].ca = id | ((u32)act << 24);
+            c.v[CNT_ENV_STEPS]++; c.v[CNT_PATH_NODES]++;
+        }
         leaf = id; kind = term ? LEAF_TERMINAL : LEAF_EVAL; tval = (float)tv;
         break;
     }
     depth_out = depth;
 }
 
-// M3: masked softmax over the legal actions (ascending), edges bump-allocated
-template <class G>
-__device__ __forceinline__ void dev_expand(const EngineDev& E, int g, u32 leaf, const LogitSrc& ls, u32& n_edges_g,
-                                           Cnt& c) {
-    Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
-    u64 legal = nd->legal;
-    u32 e0 = n_edges_g;
-    Edge* ed = E.edges + (size_t)g * E.ecap + e0;
-    int n = 0;
-    int room = E.ecap - (int)e0;
-    if (legal == 0) {  // forced pass: one edge, P = 1
-        if (room >= 1) { Edge e; e.N = 0; e.W = 0.0f; e.P = 1.0f; e.ca = (u32)kPass << 24; ed[0] = e; n = 1; }
-    } else {
-        float m = -__builtin_inff();
-        for (u64 l = legal; l; l &= l - 1) { float x = ls(ctz64(l)); if (x > m) m = x; }
-        float s = 0.0f;
-        for (u64 l = legal; l; l &= l - 1) s = s + expf_spec(ls(ctz64(l)) - m);
-        for (u64 l = legal; l && n < room; l &= l - 1) {
-            int a = ctz64(l);
-            Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(expf_spec(ls(a) - m), s); e.ca = (u32)a << 24;
-            ed[n++] = e;
-        }
-        if (popc64(legal) > room) atomicOr(&E.flags[FLAG_ERR], ERR_EDGE_OVERFLOW);
-    }
-    nd->edge0 = e0;
-    nd->info = (nd->info & ~0xFFu) | (u32)n;
-    n_edges_g = e0 + (u32)n;
-    c.v[CNT_EXPANDED]++;
-    c.v[CNT_CHILD_WRITTEN] += (u32)n;
+// k-th (0-based) set bit of m, or -1
+__device__ __forceinline__ int nth_bit(u64 m, int k) {
+    for (int j = 0; j < k; ++j) m &= m - 1;
+    return m ? ctz64(m) : -1;
 }
 
-// M4: W is stored for the mover at the parent, so the sign flips every ply
-__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int depth, float v, Cnt& c) {
+// M3: masked softmax over the legal actions (ascending), edges bump-allocated.  `legal` is the
+// leaf's legal mask (known to the caller: the root's or the node select just created).
+template <class G>
+__device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal,
+                                           const LogitSrc& ls, u32& n_edges_g, Cnt& c) {
+    Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+    const u32 e0 = n_edges_g;
+    Edge* ed = E.edges + (size_t)g * E.ecap + e0;
+    const int room = E.ecap - (int)e0;
+    int n = 0;
+    if (legal == 0) {  // forced pass: one edge, P = 1
+        if (room >= 1) {
+            if (sub == 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = 1.0f; e.ca = (u32)kPass << 24; ed[0] = e; }
+            n = 1;
+        }
+    } else {
+        n = popc64(legal);
+        if (n > room) { if (sub == 0) atomicOr(&E.flags[FLAG_ERR], ERR_EDGE_OVERFLOW); n = room; }
+        // this lane's moves: the sub-th, (sub+16)-th and (sub+32)-th legal actions
+        int a[3]; float x[3];
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a[k] = (sub + kGW * k < n) ? nth_bit(legal, sub + kGW * k) : -1;
+            x[k] = a[k] >= 0 ? ls(a[k]) : -__builtin_inff();
+            m = x[k] > m ? x[k] : m;
+        }
+#pragma unroll
+        for (int o = kGW / 2; o > 0; o >>= 1) { float m2 = __shfl_xor(m, o, kGW); m = m2 > m ? m2 : m; }
+        float ex[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ex[k] = a[k] >= 0 ? expf_spec(x[k] - m) : 0.0f;
+        float s = 0.0f;  // ascending-action serial sum (the spec's order), every lane computes it
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < kGW && kGW * k + j < n; ++j) s = s + __shfl(ex[k], j, kGW);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(ex[k], s); e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
+    }
+    if (sub == 0) {
+        nd->edge0 = e0;
+        nd->info = (nd->info & ~0xFFu) | (u32)n;
+        c.v[CNT_EXPANDED]++;
+        c.v[CNT_CHILD_WRITTEN] += (u32)n;
+    }
+    n_edges_g = e0 + (u32)n;
+}
+
+// M4: W is stored for the mover at the parent, so the sign flips every ply; one path edge per lane
+__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, Cnt& c) {
     Edge* edges = E.edges + (size_t)g * E.ecap;
-    float val = -v;
-    int dmax = depth < E.maxd ? depth : E.maxd;
-    for (int d = dmax - 1; d >= 0; --d) {
+    const int dmax = depth < E.maxd ? depth : E.maxd;
+    for (int d = sub; d < dmax; d += kGW) {
         Edge* e = edges + E.path[(size_t)d * E.B + g];
+        float val = ((dmax - 1 - d) & 1) ? v : -v;  // deepest edge gets -v
         u32 N = e->N; float W = e->W;
         e->N = N + 1u;
         e->W = W + val;
-        val = -val;
     }
-    c.v[CNT_EDGES_BACKED] += (u32)dmax;
+    if (sub == 0) c.v[CNT_EDGES_BACKED] += (u32)dmax;
 }
 
 template <class G>
@@ -243,7 +308,7 @@ __global__ void __launch_bounds__(256) k_reset_games(EngineDev E) {
         }
     }
     for (int r = 0; r < E.rounds; ++r) { E.ex_len[(size_t)r * E.B + g] = -1; E.ex_winner[(size_t)r * E.B + g] = 0; }
-    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; }
+    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0; }
 }
 
 __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, const u64* opp, const int8_t* tm) {
@@ -251,7 +316,7 @@ __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, 
     if (g >= E.B) return;
     E.g_own[g] = own[g]; E.g_opp[g] = opp[g]; E.g_to_move[g] = tm[g];
     E.g_state[g] = 0; E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
-    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; }
+    if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0; }
 }
 
 template <class G>
@@ -266,32 +331,10 @@ __global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
     E.leaf_own[g] = E.g_own[g]; E.leaf_opp[g] = E.g_opp[g];
     E.leaf_kind[g] = kind;
     if (E.compact && kind == LEAF_EVAL) {
-        u32 slot = atomicAdd(&E.flags[FLAG_NEVAL], 1u);
+        u32 slot = atomicAdd(&E.flags[FLAG_NEVAL + 1], 1u);
         E.leaf_slot[g] = slot; E.c_own[slot] = E.g_own[g]; E.c_opp[slot] = E.g_opp[g];
     }
-}
-
-template <class G>
-__global__ void __launch_bounds__(256) k_select(EngineDev E, u32 sim_idx) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    Cnt c = {};
-    if (g < E.B) {
-        uint8_t kind8 = LEAF_NONE;
-        if (E.g_state[g] == 0 && E.leaf_kind[g] != LEAF_NONE) {
-            u32 nn = E.n_nodes[g], leaf; int kind, depth; float tv;
-            dev_select<G>(E, g, sim_idx, nn, leaf, kind, depth, tv, c);
-            E.n_nodes[g] = nn; E.leaf_node[g] = leaf; E.depth[g] = (u32)depth;
-            const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
-            E.leaf_own[g] = nd->own; E.leaf_opp[g] = nd->opp;
-            kind8 = (uint8_t)kind;
-            if (E.compact && kind == LEAF_EVAL) {
-                u32 slot = atomicAdd(&E.flags[FLAG_NEVAL], 1u);
-                E.leaf_slot[g] = slot; E.c_own[slot] = nd->own; E.c_opp[slot] = nd->opp;
-            }
-        }
-        E.leaf_kind[g] = kind8;
-    }
-    cnt_flush(E, c);
+    if (g == 0) E.flags[FLAG_NEVAL] = 0;
 }
 
 // synthetic evaluators as a separate step (used by the step-by-step API)
@@ -305,31 +348,57 @@ __global__ void __launch_bounds__(256) k_eval_synth(EngineDev E, int eval_kind) 
     E.value[g] = eval_kind == BZ_EVAL_HASH ? hash_value(h) : 0.0f;
 }
 
+// One tree step for every game (16 lanes per game): [expand + backup of the previous leaf] and/or
+// [select of the next leaf].  With a net in the loop a simulation is exactly two launches:
+// this kernel and the net.
 template <class G>
-__global__ void __launch_bounds__(256) k_expand_backup(EngineDev E) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, int do_select, u32 sim_idx) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t / kGW, sub = t % kGW;
     Cnt c = {};
     if (g < E.B) {
         int kind = E.leaf_kind[g];
-        if (kind != LEAF_NONE) {
+        const bool active = E.g_state[g] == 0 && kind != LEAF_NONE;
+        if (do_expand && kind != LEAF_NONE) {
             u32 leaf = E.leaf_node[g];
+            const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
             float v;
             if (kind == LEAF_EVAL) {
                 u32 ne = E.n_edges[g];
                 size_t row = E.compact ? (size_t)E.leaf_slot[g] : (size_t)g;
                 LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + row * G::NA;
-                dev_expand<G>(E, g, leaf, ls, ne, c);
-                E.n_edges[g] = ne;
+                dev_expand<G>(E, g, sub, leaf, nd->legal, ls, ne, c);
+                if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; }
                 v = E.value[row];
-                c.v[CNT_NET_LEAVES]++;
             } else {
-                u32 info = E.nodes[(size_t)g * E.ncap + leaf].info;
-                v = (float)((int)((info >> 9) & 3u) - 1);
+                v = (float)((int)((nd->info >> 9) & 3u) - 1);
             }
-            dev_backup(E, g, (int)E.depth[g], v, c);
+            dev_backup(E, g, sub, (int)E.depth[g], v, c);
+        }
+        if (do_select) {
+            uint8_t kind8 = LEAF_NONE;
+            if (active) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // edges written above are read below
+                u32 nn = E.n_nodes[g], leaf; int k2, depth; float tv;
+                dev_select<G>(E, g, sub, sim_idx, nn, leaf, k2, depth, tv, c);
+                const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+                if (sub == 0) {
+                    E.n_nodes[g] = nn; E.leaf_node[g] = leaf; E.depth[g] = (u32)depth;
+                    u64 lo = nd->own, lp = nd->opp;
+                    E.leaf_own[g] = lo; E.leaf_opp[g] = lp;
+                    if (E.compact && k2 == LEAF_EVAL) {
+                        u32 slot = atomicAdd(&E.flags[FLAG_NEVAL + (sim_idx & 1u)], 1u);
+                        E.leaf_slot[g] = slot; E.c_own[slot] = lo; E.c_opp[slot] = lp;
+                    }
+                }
+                kind8 = (uint8_t)k2;
+            }
+            if (sub == 0) E.leaf_kind[g] = kind8;
+            if (t == 0) E.flags[FLAG_NEVAL + ((sim_idx + 1u) & 1u)] = 0;  // the buffer the NEXT select packs into
+        } else if (t == 0) {  // expand-only step (end of a search / step API): nothing is packed any more
+            E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0;
         }
     }
-    if (g == 0) E.flags[FLAG_NEVAL] = 0;  // consumed by the evaluator; the next select packs from 0
     cnt_flush(E, c);
 }
 
@@ -337,25 +406,36 @@ __global__ void __launch_bounds__(256) k_expand_backup(EngineDev E) {
 // root expansion + sims x (select, expand, backup), no host round trip.
 template <class G>
 __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t / kGW, sub = t % kGW;
     Cnt c = {};
-    if (g < E.B && E.g_state[g] == 0 && dev_root_init<G>(E, g)) {
-        u32 nn = 1, ne = 0;
-        LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
-        ls.h = hash_pos(E.g_own[g], E.g_opp[g]);
-        dev_expand<G>(E, g, 0, ls, ne, c);
-        for (int s = 0; s < E.sims; ++s) {
-            u32 leaf; int kind, depth; float v;
-            dev_select<G>(E, g, (u32)s, nn, leaf, kind, depth, v, c);
-            if (kind == LEAF_EVAL) {
-                const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
-                ls.h = hash_pos(nd->own, nd->opp);
-                dev_expand<G>(E, g, leaf, ls, ne, c);
-                v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
+    if (g < E.B && E.g_state[g] == 0) {
+        bool ok = true;
+        if (sub == 0) ok = dev_root_init<G>(E, g);
+        ok = __shfl((int)ok, 0, kGW) != 0;
+        if (ok) {
+            u32 nn = 1, ne = 0;
+            LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
+            const u64 rown = E.g_own[g], ropp = E.g_opp[g];
+            ls.h = hash_pos(rown, ropp);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            dev_expand<G>(E, g, sub, 0, G::legal(rown, ropp), ls, ne, c);
+            for (int s = 0; s < E.sims; ++s) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this group's stores -> its loads
+                u32 leaf; int kind, depth; float v;
+                dev_select<G>(E, g, sub, (u32)s, nn, leaf, kind, depth, v, c);
+                if (kind == LEAF_EVAL) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+                    u64 lo = nd->own, lp = nd->opp;
+                    ls.h = hash_pos(lo, lp);
+                    dev_expand<G>(E, g, sub, leaf, G::legal(lo, lp), ls, ne, c);
+                    v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
+                }
+                dev_backup(E, g, sub, depth, v, c);
             }
-            dev_backup(E, g, depth, v, c);
+            if (sub == 0) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
         }
-        E.n_nodes[g] = nn; E.n_edges[g] = ne;
     }
     cnt_flush(E, c);
 }
@@ -452,6 +532,7 @@ struct bz_engine {
     EngineDev dev;
     bz_net* net;
     int64_t bytes;
+    int pack_parity;  // which NEVAL buffer the last root_begin / select packed into
 };
 
 namespace {
@@ -463,7 +544,8 @@ struct Carver {
 struct Offsets {
     int64_t nodes, edges, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
         path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
-        ex_act, ex_len, ex_winner, root_N, root_W, root_P, counters, flags, total;
+        ex_act, ex_len, ex_winner, root_N, root_W, root_P, counters, cnt_slots, flags, total;
+    int n_cnt_slots;
     int ncap, ecap, na, maxd;
 };
 
@@ -495,14 +577,29 @@ Offsets carve(const bz_engine_cfg& c) {
     o.ex_z = k.take(R * B * T); o.ex_mover = k.take(R * B * T); o.ex_act = k.take(R * B * T);
     o.ex_len = k.take(R * B * 4); o.ex_winner = k.take(R * B);
     o.root_N = k.take(B * o.na * 4); o.root_W = k.take(B * o.na * 4); o.root_P = k.take(B * o.na * 4);
-    o.counters = k.take(16 * 8); o.flags = k.take(FLAG_N * 4);
+    o.counters = k.take(16 * 8);
+    o.n_cnt_slots = (int)((B * kGW + 63) / 64) + 4;  // one slot per wave of the widest (group) launch
+    o.cnt_slots = k.take((int64_t)o.n_cnt_slots * CNT_N * 8);
+    o.flags = k.take(FLAG_N * 4);
     o.total = k.off;
     return o;
 }
 
 template <class T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 inline dim3 grid_of(int B) { return dim3((B + 255) / 256); }
+inline dim3 grid_groups(int B) { return dim3(((size_t)B * kGW + 255) / 256); }
 }  // namespace
+
+#define BZ_DISPATCH_G(e, KERNEL, stream, ...)                                                           \
+    do {                                                                                                \
+        if ((e)->cfg.game == BZ_GAME_TTT)                                                               \
+            hipLaunchKernelGGL(KERNEL<TicTacToe>, grid_groups((e)->dev.B), dim3(256), 0, (hipStream_t)(stream), \
+                               __VA_ARGS__);                                                            \
+        else                                                                                            \
+            hipLaunchKernelGGL(KERNEL<Reversi>, grid_groups((e)->dev.B), dim3(256), 0, (hipStream_t)(stream),   \
+                               __VA_ARGS__);                                                            \
+        BZ_LAUNCH_CHECK(#KERNEL);                                                                       \
+    } while (0)
 
 #define BZ_DISPATCH(e, KERNEL, stream, ...)                                                             \
     do {                                                                                                \
@@ -528,7 +625,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_engine_create: workspace must be 256-byte aligned");
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
-    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total;
+    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1;
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
@@ -549,6 +646,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.ex_len = at<int32_t>(ws, o.ex_len); d.ex_winner = at<int8_t>(ws, o.ex_winner);
     d.root_N = at<u32>(ws, o.root_N); d.root_W = at<float>(ws, o.root_W); d.root_P = at<float>(ws, o.root_P);
     d.counters = at<u64>(ws, o.counters); d.flags = at<u32>(ws, o.flags);
+    d.cnt_slots = at<u64>(ws, o.cnt_slots); d.n_cnt_slots = o.n_cnt_slots;
     bz_engine_layout& l = e->lay;
     l.ex_own = o.ex_own; l.ex_opp = o.ex_opp; l.ex_pi = o.ex_pi; l.ex_z = o.ex_z; l.ex_mover = o.ex_mover;
     l.ex_act = o.ex_act; l.ex_len = o.ex_len; l.ex_winner = o.ex_winner; l.root_N = o.root_N; l.root_W = o.root_W;
@@ -576,6 +674,15 @@ BZ_EXPORT int32_t bz_engine_set_net(bz_engine* e, bz_net* net) {
 BZ_EXPORT int32_t bz_engine_reset_counters(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     BZ_HIP(hipMemsetAsync(e->dev.counters, 0, 16 * 8, (hipStream_t)stream));
+    BZ_HIP(hipMemsetAsync(e->dev.cnt_slots, 0, (size_t)e->dev.n_cnt_slots * CNT_N * 8, (hipStream_t)stream));
+    return BZ_OK;
+}
+
+/* fold the per-wave counter slots into the counters[16] array of the layout (async) */
+BZ_EXPORT int32_t bz_engine_sum_counters(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    hipLaunchKernelGGL(k_sum_counters, dim3(1), dim3(256), 0, (hipStream_t)stream, e->dev);
+    BZ_LAUNCH_CHECK("k_sum_counters");
     return BZ_OK;
 }
 
@@ -596,19 +703,21 @@ BZ_EXPORT int32_t bz_engine_set_roots(bz_engine* e, const uint64_t* own, const u
 BZ_EXPORT int32_t bz_engine_root_begin(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     BZ_DISPATCH(e, k_root_begin, stream, e->dev);
+    e->pack_parity = 1;
     return BZ_OK;
 }
 
-static int32_t select_step(bz_engine* e, uint32_t sim_idx, void* stream) {
-    ProfScope ps(BZ_PROF_SELECT, stream);
-    BZ_DISPATCH(e, k_select, stream, e->dev, sim_idx);
+static int32_t tree_step(bz_engine* e, int do_expand, int do_select, uint32_t sim_idx, void* stream) {
+    ProfScope ps(do_select ? BZ_PROF_SELECT : BZ_PROF_EXPAND_BACKUP, stream);
+    BZ_DISPATCH_G(e, k_tree_step, stream, e->dev, do_expand, do_select, sim_idx);
+    if (do_select) e->pack_parity = (int)(sim_idx & 1u);
     return BZ_OK;
 }
 
 /* sim_index = number of simulations already completed in this search (the root's visit sum) */
 BZ_EXPORT int32_t bz_engine_select(bz_engine* e, uint32_t sim_index, void* stream) {
     BZ_REQUIRE(e, "null engine");
-    return select_step(e, sim_index, stream);
+    return tree_step(e, 0, 1, sim_index, stream);
 }
 
 BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
@@ -623,14 +732,12 @@ BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
     BZ_REQUIRE(e->cfg.game == BZ_GAME_REVERSI, "bz_engine_evaluate: the conv net is 8x8 Reversi only");
     // leaves were packed by select: evaluate only the first flags[NEVAL] slots (device-side count)
     return bz_net_forward_dev(e->net, ek == BZ_EVAL_NET_BF16, e->dev.c_own, e->dev.c_opp, e->dev.B,
-                              e->dev.flags + FLAG_NEVAL, e->dev.logits, e->dev.value, stream);
+                              e->dev.flags + FLAG_NEVAL + e->pack_parity, e->dev.logits, e->dev.value, stream);
 }
 
 BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
-    ProfScope ps(BZ_PROF_EXPAND_BACKUP, stream);
-    BZ_DISPATCH(e, k_expand_backup, stream, e->dev);
-    return BZ_OK;
+    return tree_step(e, 1, 0, 0, stream);
 }
 
 BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
@@ -638,20 +745,18 @@ BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     int ek = e->cfg.eval_kind;
     if (ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) {
         ProfScope ps(BZ_PROF_SEARCH_FUSED, stream);
-        BZ_DISPATCH(e, k_search_fused, stream, e->dev, ek);
+        BZ_DISPATCH_G(e, k_search_fused, stream, e->dev, ek);
         return BZ_OK;
     }
     BZ_REQUIRE(ek != BZ_EVAL_EXTERNAL, "bz_engine_search: BZ_EVAL_EXTERNAL callers drive the step API");
     int32_t rc;
     if ((rc = bz_engine_root_begin(e, stream)) != BZ_OK) return rc;
     if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
-    if ((rc = bz_engine_expand_backup(e, stream)) != BZ_OK) return rc;
-    for (int s = 0; s < e->cfg.sims; ++s) {
-        if ((rc = select_step(e, (uint32_t)s, stream)) != BZ_OK) return rc;
+    for (int s = 0; s < e->cfg.sims; ++s) {  // expand+backup of leaf s-1 (s = 0: the root) fused with select s
+        if ((rc = tree_step(e, 1, 1, (uint32_t)s, stream)) != BZ_OK) return rc;
         if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
-        if ((rc = bz_engine_expand_backup(e, stream)) != BZ_OK) return rc;
     }
-    return BZ_OK;
+    return tree_step(e, 1, 0, 0, stream);
 }
 
 BZ_EXPORT int32_t bz_engine_root_stats(bz_engine* e, void* stream) {

@@ -138,6 +138,7 @@ class SelfPlayEngine:
         return N, W, P
 
     def counters(self):
+        self._call(_lib.lib().bz_engine_sum_counters)
         c = self._view(self.lay.counters, torch.int64, (16,)).cpu().numpy()
         return dict(zip(_lib.COUNTER_NAMES, (int(v) for v in c[:8])))
 

@@ -195,6 +195,8 @@ int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream);
 int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
                          int32_t* error_flags);
 int32_t bz_engine_reset_counters(bz_engine* e, void* stream);
+/* fold the kernels' per-wave counter slots into the layout's counters[16] array (async) */
+int32_t bz_engine_sum_counters(bz_engine* e, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* In-library kernel timers: HIP events recorded on the launch stream around  */
