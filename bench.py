@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,15 +135,28 @@ def main():
         mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
         net = DeviceNet.from_module(mod, B, dev)
         rounds = 2 + (W + K) // 40
-        eng = SelfPlayEngine("reversi", B, sims, "net_bf16", net, temp_moves=8, openings=1, seed=0, rounds=rounds,
-                             game_id_base=rank * B, game_id_stride=world * B, device=dev, stagger=PLIES_PER_GAME)
-        eng.reset_games()
+        # NS independent pipelines of B/NS games, each on its own HIP stream: the tree step of one
+        # overlaps the net kernel of the other and their net launches fill each other's tail wave.
+        NS = max(1, args.streams)
+        assert B % NS == 0
+        Bs = B // NS
+        streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+        engs = [SelfPlayEngine("reversi", Bs, sims, "net_bf16", net, temp_moves=8, openings=1, seed=0, rounds=rounds,
+                               game_id_base=rank * B + i * Bs, game_id_stride=world * B, device=dev,
+                               stagger=PLIES_PER_GAME) for i in range(NS)]
+        eng = engs[0]
+        for e in engs:
+            e.reset_games()
+        torch.cuda.synchronize()
 
         def step():
-            eng.search()
-            eng.play(True)
+            for e, st in zip(engs, streams):
+                with torch.cuda.stream(st):
+                    e.search()
+                    e.play(True)
     else:
         eng = SelfPlayEngine("ttt", B, sims, "uniform", game_id_base=rank * B, game_id_stride=world * B, device=dev)
+        engs = [eng]
 
         def step():
             eng.reset_games()
@@ -152,21 +166,25 @@ def main():
 
     for _ in range(W):
         step()
-    _, fin0 = eng.status()
-    eng.reset_counters()
+    torch.cuda.synchronize()
+    fin0 = sum(e.status()[1] for e in engs)
+    for e in engs:
+        e.reset_counters()
     L.bz_profile_reset()
     L.bz_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         step()
+    torch.cuda.synchronize()
     if world > 1:  # the one exchange step: pool this iteration's (s, pi, z)
-        pooled = all_gather_example_tensors(eng.example_tensors())
-        del pooled
+        for e in engs:
+            pooled = all_gather_example_tensors(e.example_tensors())
+            del pooled
     barrier()
     dt = time.perf_counter() - t0
     L.bz_profile_enable(0)
-    _, fin1 = eng.status()
+    fin1 = sum(e.status()[1] for e in engs)
     if not reversi:
         fin1, fin0 = K * B, 0
     games = float(fin1 - fin0)
@@ -175,7 +193,10 @@ def main():
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, games = float(tmax[0]), float(tsum[1])
-    cnt = eng.counters()
+    cnt = {}
+    for e in engs:
+        for k, v in e.counters().items():
+            cnt[k] = cnt.get(k, 0) + v
     prof = _lib.profile_read()
 
     if rank == 0:
@@ -189,6 +210,7 @@ def main():
                              "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8,
                              "openings": 12, "net": "stem + 6 residual blocks x 128 ch, random init seed 0",
                              "step": "one move for all concurrent games (steady-state pool, staggered starts)",
+                             "pipelines": f"{NS} x {Bs} games on separate HIP streams",
                              "parallelism": f"games sharded over {n_gpus} GPU(s), one all-gather of examples"}
             launches, timed, ms = prof["tower"]
             avg_ms = ms / max(timed, 1)
@@ -196,11 +218,24 @@ def main():
             pos_per_launch = cnt["n_net_leaves"] / max(launches, 1)
             flop_per_launch = pos_per_launch * NET_FLOP_PER_POS  # stem + tower + heads are ONE kernel
             ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
+            union_ms, sum_ms = _lib.profile_union_ms("tower")
+            conc = sum_ms / union_ms if union_ms else 1.0
+            chip = cnt["n_net_leaves"] * NET_FLOP_PER_POS * (timed / max(launches, 1)) / (union_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "k_tower_bf16 (stem + 12 conv3x3 + heads, fused)",
                                "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "launches": launches,
                                "avg_launch_ms": avg_ms, "positions_per_launch": pos_per_launch,
-                               "flop_per_launch": flop_per_launch}
+                               "flop_per_launch": flop_per_launch,
+                               # launches of the NS pipelines overlap on the chip: per-launch duration is
+                               # shared time.  chip-level = flops of all launches / union of their intervals
+                               "concurrent_launches": conc, "achieved_chip": chip,
+                               "frac_chip": chip / MFMA_PEAK_TFLOPS}
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_tower_bf16"]
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes at 4096 positions per launch (profiles/r01_pmc_traffic.json)"
+            except Exception:
+                pass
             tb = tree_bytes(cnt)
             tree_ms = prof["select"][2] * prof["select"][0] / max(prof["select"][1], 1) + \
                 prof["expand_backup"][2] * prof["expand_backup"][0] / max(prof["expand_backup"][1], 1)

@@ -71,6 +71,7 @@ _SIGS = {
     "bz_profile_enable": (i32, [i32]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
     "bz_profile_reset": (i32, []),
+    "bz_profile_intervals": (i32, [i32, vp, vp, i64, C.POINTER(i64)]),
 }
 ABI_SYMBOLS = tuple(_SIGS)
 
@@ -124,3 +125,25 @@ def profile_read():
         check(lib().bz_profile_read(i, C.byref(a), C.byref(b), C.byref(t)))
         out[name] = (a.value, b.value, t.value)
     return out
+
+
+def profile_union_ms(slot_name, cap=20000):
+    """(union busy time, summed duration) in ms of a slot's timed launches (they may overlap across streams)"""
+    import numpy as np
+    st = np.zeros(cap, np.float64)
+    en = np.zeros(cap, np.float64)
+    n = i64()
+    check(lib().bz_profile_intervals(PROF_SLOTS.index(slot_name), st.ctypes.data, en.ctypes.data, cap, C.byref(n)))
+    st, en = st[:n.value], en[:n.value]
+    order = np.argsort(st)
+    union, cur_s, cur_e = 0.0, None, None
+    for a, b in zip(st[order], en[order]):
+        if cur_e is None or a > cur_e:
+            if cur_e is not None:
+                union += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    if cur_e is not None:
+        union += cur_e - cur_s
+    return union, float((en - st).sum())

@@ -67,6 +67,23 @@ BZ_EXPORT int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* time
     return BZ_OK;
 }
 
+/* start/end of every timed launch of a slot, in ms relative to the slot's first recorded event
+ * (launches on different streams may overlap; the caller can form the union) */
+BZ_EXPORT int32_t bz_profile_intervals(int32_t slot, double* starts_ms, double* ends_ms, int64_t cap, int64_t* n) {
+    BZ_REQUIRE(slot >= 0 && slot < BZ_PROF_N && starts_ms && ends_ms && n, "bz_profile_intervals: bad arguments");
+    BZ_HIP(hipDeviceSynchronize());
+    bz::ProfSlot& p = bz::g_prof[slot];
+    int64_t m = p.used < cap ? p.used : cap;
+    for (int64_t i = 0; i < m; ++i) {
+        float a = 0, b = 0;
+        BZ_HIP(hipEventElapsedTime(&a, p.ev[0], p.ev[2 * i]));
+        BZ_HIP(hipEventElapsedTime(&b, p.ev[0], p.ev[2 * i + 1]));
+        starts_ms[i] = a; ends_ms[i] = b;
+    }
+    *n = m;
+    return BZ_OK;
+}
+
 BZ_EXPORT int32_t bz_abi_version(void) { return BZ_ABI_VERSION; }
 BZ_EXPORT const char* bz_last_error(void) { return bz::g_err; }
 BZ_EXPORT int32_t bz_device_count(void) {

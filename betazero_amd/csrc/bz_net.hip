@@ -180,6 +180,9 @@ constexpr int kTileBytes = 65 * 256;      // 64 cells x 256 B + one zero cell
 #ifndef BZ_TOWER_P
 #define BZ_TOWER_P 4
 #endif
+#ifndef BZ_LAST_TAP_TILE_MAJOR
+#define BZ_LAST_TAP_TILE_MAJOR 0
+#endif
 constexpr int kPosPerWG = BZ_TOWER_P;    // positions resident per workgroup (4: one WG per CU; 2: two WGs per CU)
 template <int P> constexpr int buf_bytes() { return P * kTileBytes; }
 template <int P> constexpr int tower_lds() { return 2 * P * kTileBytes; }
@@ -299,6 +302,60 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[P][2], char* out, bool se
         }
 }
 
+// epilogue of ONE accumulator tile (position p, cell tile nt)
+__device__ __forceinline__ void epilogue_tile(const f32x16& a, char* out, bool second, const f32x4 (&bq)[4], int p, int nt,
+                                              int w, int r, int h) {
+    const int cell = 32 * nt + r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int off = p * kTileBytes + cell_off(cell, 4 * w + q) + 8 * h;
+        f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+        v = v + bq[q];
+        if (second) {
+            bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+            v = v + __builtin_convertvector(sk, f32x4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+        *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
+    }
+}
+
+// The LAST tap of a layer runs tile-major (8 k-steps of one accumulator tile, then the next
+// tile), so the epilogue of tile t (VALU + LDS) sits between the MFMAs of tile t+1 instead of
+// after all of them: roughly half of the epilogue hides in MFMA issue gaps.
+template <int S, int P>
+__device__ __forceinline__ void last_tap(f32x16 (&acc)[P][2], bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap,
+                                         const char* in, char* out, bool second, const float* __restrict__ bl,
+                                         const int (&boff)[2], int w, int r, int h) {
+    bf16x8 (&use)[8] = S ? A1 : A0;
+    bf16x8 (&nxt)[8] = S ? A0 : A1;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) nxt[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
+    ap += 8 * 256;
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q);
+    bf16x8 bt[2][8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) bt[0][kc] = *reinterpret_cast<const bf16x8*>(in + (boff[0] ^ (kc << 5)));
+#pragma unroll
+    for (int t = 0; t < 2 * P; ++t) {
+        const int p = t >> 1, nt = t & 1;
+        if (t + 1 < 2 * P) {
+            const int p2 = (t + 1) >> 1, nt2 = (t + 1) & 1;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc)
+                bt[(t + 1) & 1][kc] = *reinterpret_cast<const bf16x8*>(in + p2 * kTileBytes + (boff[nt2] ^ (kc << 5)));
+        }
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc)
+            acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use[kc], bt[t & 1][kc], acc[p][nt], 0, 0, 0);
+        if (t > 0) epilogue_tile(acc[(t - 1) >> 1][(t - 1) & 1], out, second, bq, (t - 1) >> 1, (t - 1) & 1, w, r, h);
+    }
+    epilogue_tile(acc[P - 1][1], out, second, bq, P - 1, 1, w, r, h);
+}
+
 // One conv3x3 layer over the 4 resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
 // S0 = register set that holds tap 0's weight fragments on entry (the other one on exit).
 template <int S0, int P>
@@ -314,28 +371,19 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     tap_off(0, r, h, boff);
     bf16x8 b0[P][2], b1[P][2];
     load_b<P>(b0, in, boff, 0);
-    if (S0 == 0) {
 #pragma unroll 1
-        for (int t = 0; t < 8; t += 2) {
-            tap_step<0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
-            tap_step<1, P>(acc, A0, A1, ap, in, boff, t + 2, r, h, b0, b1);
-        }
-        tap_step<0, P>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
-    } else {
-        tap_step<1, P>(acc, A0, A1, ap, in, boff, 1, r, h, b0, b1);
-#pragma unroll 1
-        for (int t = 1; t < 9; t += 2) {
-            tap_step<0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
-            tap_step<1, P>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
-        }
+    for (int t = 0; t < 8; t += 2) {  // taps 0..7; tap 8 uses the same register set as tap 0
+        tap_step<S0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
+        tap_step<1 - S0, P>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
     }
+#if BZ_LAST_TAP_TILE_MAJOR
     BZ_STAMP(t1);
-#ifdef BZ_EXP_NO_EPI
-    if (acc[0][0][0] == 12345.678f) out[0] = 1;  // keep acc live
-    __syncthreads();
-    return;
-#endif
+    last_tap<S0, P>(acc, A0, A1, ap, in, out, second, bl, boff, w, r, h);
+#else
+    tap_step<S0, P>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
+    BZ_STAMP(t1);
     epilogue<P>(acc, out, second, bl, w, r, h);
+#endif
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);

@@ -209,6 +209,9 @@ int32_t bz_profile_enable(int32_t on);
  * carried events (capped), total_ms = sum of their durations */
 int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* timed, double* total_ms);
 int32_t bz_profile_reset(void);
+/* start/end (ms, relative to the slot's first event) of every timed launch; launches issued on
+ * different streams may overlap in time */
+int32_t bz_profile_intervals(int32_t slot, double* starts_ms, double* ends_ms, int64_t cap, int64_t* n);
 
 #ifdef __cplusplus
 }
