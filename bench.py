@@ -104,10 +104,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("BZ_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
     dev = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -179,7 +184,10 @@ def main():
     torch.cuda.synchronize()
     if world > 1:  # the one exchange step: pool this iteration's (s, pi, z)
         for e in engs:
-            pooled = all_gather_example_tensors(e.example_tensors())
+            t = e.example_tensors()
+            if backend != "nccl":
+                t = {k: v.cpu() for k, v in t.items()}
+            pooled = all_gather_example_tensors(t)
             del pooled
     barrier()
     dt = time.perf_counter() - t0
@@ -189,7 +197,7 @@ def main():
         fin1, fin0 = K * B, 0
     games = float(fin1 - fin0)
     if world > 1:
-        t = torch.tensor([dt, games], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, games], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, games = float(tmax[0]), float(tsum[1])

@@ -45,6 +45,8 @@ _SIGS = {
     "bz_reversi_step_batch": (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
     "bz_reversi_legal_batch": (i32, [vp, vp, i64, vp, vp]),
     "bz_ttt_step_batch": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "bz_augment_d4_batch": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
+    "bz_net_update": (i32, [vp, vp, vp]),
     "bz_net_param_count": (i64, [i32, i32, i32]),
     "bz_net_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "bz_net_create": (i32, [i32, i32, i32, i32, vp, vp, i64, vp, C.POINTER(vp)]),

@@ -208,6 +208,62 @@ __global__ void __launch_bounds__(256) k_ttt_step(const uint16_t* __restrict__ o
     }
 }
 
+// ---------------------------------------------------------------- D4 augmentation (SL/train.py:27-36)
+// out[r][c] = x[src(r, c)] for the reference's 8 transforms, in its order:
+//  0 id, 1 flip(dims=[0]), 2 flip(dims=[1]), 3 rot90(1), 4 rot90(2), 5 rot90(3), 6 t(), 7 flip(dims=[0]).t()
+// (7 equals 5 in the reference -- torch semantics -- and is kept as is; its dedupe removes the copy)
+__host__ __device__ inline void d4_src(int t, int n, int r, int c, int* sr, int* sc) {
+    switch (t) {
+    case 0: *sr = r; *sc = c; break;
+    case 1: *sr = n - 1 - r; *sc = c; break;
+    case 2: *sr = r; *sc = n - 1 - c; break;
+    case 3: *sr = c; *sc = n - 1 - r; break;
+    case 4: *sr = n - 1 - r; *sc = n - 1 - c; break;
+    case 6: *sr = c; *sc = r; break;
+    default: *sr = n - 1 - c; *sc = r; break;  // 5 and 7
+    }
+}
+
+// thread = (row i, transform t): bitboards permuted bit by bit, pi permuted through the same map
+__global__ void __launch_bounds__(256) k_augment_d4(const u64* __restrict__ own, const u64* __restrict__ opp,
+                                                    const float* __restrict__ pi, int64_t n, int size, int na,
+                                                    u64* __restrict__ own8, u64* __restrict__ opp8,
+                                                    float* __restrict__ pi8, u64* __restrict__ key8) {
+    int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (id >= n * 8) return;
+    int64_t i = id >> 3;
+    int t = (int)(id & 7);
+    const int stride = size == 3 ? 3 : 8;
+    u64 a = own[i], b = opp[i], oa = 0, ob = 0;
+    const float* src = pi + i * na;
+    float* dst = pi8 + id * na;
+    u64 h = 0x243F6A8885A308D3ULL;
+    for (int r = 0; r < size; ++r)
+        for (int c = 0; c < size; ++c) {
+            int sr, sc;
+            d4_src(t, size, r, c, &sr, &sc);
+            int sb = stride * sr + sc, db = stride * r + c;
+            oa |= ((a >> sb) & 1ULL) << db;
+            ob |= ((b >> sb) & 1ULL) << db;
+            float p = src[size * sr + sc];
+            dst[size * r + c] = p;
+            h = (h ^ (u64)__float_as_uint(p)) * 0x100000001B3ULL;
+        }
+    for (int k = size * size; k < na; ++k) {  // actions beyond the board (Reversi's pass) do not move
+        float p = src[k];
+        dst[k] = p;
+        h = (h ^ (u64)__float_as_uint(p)) * 0x100000001B3ULL;
+    }
+    own8[id] = oa; opp8[id] = ob;
+    if (key8) {  // 64-bit content key of (s, pi) for the dedupe pass
+        h ^= oa * 0x9E3779B97F4A7C15ULL;
+        h = (h ^ (h >> 29)) * 0xBF58476D1CE4E5B9ULL;
+        h ^= ob * 0xC2B2AE3D27D4EB4FULL;
+        h = (h ^ (h >> 32)) * 0x94D049BB133111EBULL;
+        key8[id] = h ^ (h >> 31);
+    }
+}
+
 static int grid_for(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));  // <= 256 CUs x 8 blocks, grid-stride the rest
@@ -242,5 +298,18 @@ BZ_EXPORT int32_t bz_ttt_step_batch(const uint16_t* own, const uint16_t* opp, co
     hipLaunchKernelGGL(k_ttt_step, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, action, to_move,
                        n, own_next, opp_next, legal_next, status, winner);
     BZ_LAUNCH_CHECK("k_ttt_step");
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_augment_d4_batch(const uint64_t* own, const uint64_t* opp, const float* pi, int64_t n, int32_t size,
+                                      int32_t na, uint64_t* own8, uint64_t* opp8, float* pi8, uint64_t* key8,
+                                      void* stream) {
+    BZ_REQUIRE(n >= 0 && own && opp && pi && own8 && opp8 && pi8, "bz_augment_d4_batch: null pointer");
+    BZ_REQUIRE((size == 3 || size == 8) && na >= size * size, "bz_augment_d4_batch: size must be 3 or 8, na >= size*size");
+    if (n == 0) return BZ_OK;
+    int64_t blocks = (n * 8 + 255) / 256;
+    hipLaunchKernelGGL(k_augment_d4, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, own, opp, pi, n, (int)size,
+                       (int)na, own8, opp8, pi8, key8);
+    BZ_LAUNCH_CHECK("k_augment_d4");
     return BZ_OK;
 }

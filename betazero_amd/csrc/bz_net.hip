@@ -46,6 +46,7 @@ struct bz_net {
     // activations (device)
     float *act_a, *act_b;            // f32 path: [max_batch][64][C] x 2
     __bf16* act_h;                   // bf16 path: [max_batch][64][C]
+    void* ws_base;
 };
 
 namespace {
@@ -586,41 +587,11 @@ uint16_t f2bf(float f) {
 template <class T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 }  // namespace
 
-BZ_EXPORT int64_t bz_net_param_count(int32_t C, int32_t NB, int32_t VH) {
-    int64_t n = (int64_t)C * 2 * 9 + C;
-    n += (int64_t)NB * 2 * ((int64_t)C * C * 9 + C);
-    n += 2LL * C + 2 + 65 * 128 + 65;
-    n += (int64_t)C + 1 + (int64_t)VH * 64 + VH + VH + 1;
-    return n;
-}
-
-BZ_EXPORT int64_t bz_net_workspace_bytes(int32_t C, int32_t NB, int32_t VH, int32_t max_batch) {
-    if (!shape_ok(C, NB, VH, max_batch)) { set_error("bz_net_workspace_bytes: unsupported shape"); return -1; }
-    return net_carve(C, NB, VH, max_batch).total;
-}
-
-BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_batch, const float* p, void* ws,
-                                int64_t bytes, void* stream, bz_net** out) {
-    BZ_REQUIRE(shape_ok(C, NB, VH, max_batch) && p && ws && out, "bz_net_create: unsupported shape or null pointer");
-    if (bz_device_count() <= 0) { set_error("bz_net_create: no HIP device (the net has no CPU path)"); return BZ_ENOGPU; }
-    NetOffsets o = net_carve(C, NB, VH, max_batch);
-    if (bytes < o.total) { set_error("bz_net_create: workspace too small"); return BZ_ENOMEM; }
-    BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_net_create: workspace must be 256-byte aligned");
-    bz_net* n = new (std::nothrow) bz_net();
-    if (!n) { set_error("out of host memory"); return BZ_ENOMEM; }
-    n->C = C; n->NB = NB; n->VH = VH; n->max_batch = max_batch;
-    n->stem_w = at<float>(ws, o.stem_w); n->stem_b = at<float>(ws, o.stem_b);
-    n->conv_w = at<float>(ws, o.conv_w); n->conv_b = at<float>(ws, o.conv_b);
-    n->conv_wf = C == kTC ? at<__bf16>(ws, o.conv_wf) : nullptr;
-    n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
-    n->pol_w = at<float>(ws, o.pol_w); n->pol_b = at<float>(ws, o.pol_b);
-    n->polfc_wT = at<float>(ws, o.polfc_wT); n->polfc_b = at<float>(ws, o.polfc_b);
-    n->val_w = at<float>(ws, o.val_w); n->val_b = at<float>(ws, o.val_b);
-    n->v1_wT = at<float>(ws, o.v1_wT); n->v1_b = at<float>(ws, o.v1_b);
-    n->v2_w = at<float>(ws, o.v2_w); n->v2_b = at<float>(ws, o.v2_b);
-    n->act_a = at<float>(ws, o.act_a); n->act_b = at<float>(ws, o.act_b); n->act_h = at<__bf16>(ws, o.act_h);
-
-    // ---- host repack into one staging image of the parameter region, one H2D copy
+// host repack of the flat torch-layout parameter vector into the kernels' layouts, one H2D copy
+static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
+    const int C = n->C, NB = n->NB, VH = n->VH;
+    NetOffsets o = net_carve(C, NB, VH, n->max_batch);
+    void* ws = n->ws_base;
     int64_t param_bytes = o.act_a;
     std::vector<char> img((size_t)param_bytes, 0);
     auto F = [&](int64_t off) { return reinterpret_cast<float*>(img.data() + off); };
@@ -690,10 +661,49 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
                     hf[((size_t)kc * 64 + ln) * 8 + j] = f2bf(v);
                 }
     }
-    hipStream_t s = (hipStream_t)stream;
     hipError_t e1 = hipMemcpyAsync(ws, img.data(), (size_t)param_bytes, hipMemcpyHostToDevice, s);
     hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(s) : e1;
-    if (e2 != hipSuccess) { delete n; return hip_fail(e2, "bz_net_create upload"); }
+    if (e2 != hipSuccess) return hip_fail(e2, "bz_net upload");
+    return BZ_OK;
+}
+
+BZ_EXPORT int64_t bz_net_param_count(int32_t C, int32_t NB, int32_t VH) {
+    int64_t n = (int64_t)C * 2 * 9 + C;
+    n += (int64_t)NB * 2 * ((int64_t)C * C * 9 + C);
+    n += 2LL * C + 2 + 65 * 128 + 65;
+    n += (int64_t)C + 1 + (int64_t)VH * 64 + VH + VH + 1;
+    return n;
+}
+
+BZ_EXPORT int64_t bz_net_workspace_bytes(int32_t C, int32_t NB, int32_t VH, int32_t max_batch) {
+    if (!shape_ok(C, NB, VH, max_batch)) { set_error("bz_net_workspace_bytes: unsupported shape"); return -1; }
+    return net_carve(C, NB, VH, max_batch).total;
+}
+
+BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_batch, const float* p, void* ws,
+                                int64_t bytes, void* stream, bz_net** out) {
+    BZ_REQUIRE(shape_ok(C, NB, VH, max_batch) && p && ws && out, "bz_net_create: unsupported shape or null pointer");
+    if (bz_device_count() <= 0) { set_error("bz_net_create: no HIP device (the net has no CPU path)"); return BZ_ENOGPU; }
+    NetOffsets o = net_carve(C, NB, VH, max_batch);
+    if (bytes < o.total) { set_error("bz_net_create: workspace too small"); return BZ_ENOMEM; }
+    BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_net_create: workspace must be 256-byte aligned");
+    bz_net* n = new (std::nothrow) bz_net();
+    if (!n) { set_error("out of host memory"); return BZ_ENOMEM; }
+    n->C = C; n->NB = NB; n->VH = VH; n->max_batch = max_batch;
+    n->stem_w = at<float>(ws, o.stem_w); n->stem_b = at<float>(ws, o.stem_b);
+    n->conv_w = at<float>(ws, o.conv_w); n->conv_b = at<float>(ws, o.conv_b);
+    n->conv_wf = C == kTC ? at<__bf16>(ws, o.conv_wf) : nullptr;
+    n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
+    n->pol_w = at<float>(ws, o.pol_w); n->pol_b = at<float>(ws, o.pol_b);
+    n->polfc_wT = at<float>(ws, o.polfc_wT); n->polfc_b = at<float>(ws, o.polfc_b);
+    n->val_w = at<float>(ws, o.val_w); n->val_b = at<float>(ws, o.val_b);
+    n->v1_wT = at<float>(ws, o.v1_wT); n->v1_b = at<float>(ws, o.v1_b);
+    n->v2_w = at<float>(ws, o.v2_w); n->v2_b = at<float>(ws, o.v2_b);
+    n->act_a = at<float>(ws, o.act_a); n->act_b = at<float>(ws, o.act_b); n->act_h = at<__bf16>(ws, o.act_h);
+
+    n->ws_base = ws;
+    int32_t urc = upload_params(n, p, (hipStream_t)stream);
+    if (urc != BZ_OK) { delete n; return urc; }
     if (C == kTC) {
         hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<kPosPerWG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
@@ -704,6 +714,11 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
 }
 
 BZ_EXPORT int32_t bz_net_destroy(bz_net* net) { delete net; return BZ_OK; }
+
+BZ_EXPORT int32_t bz_net_update(bz_net* net, const float* params_host, void* stream) {
+    BZ_REQUIRE(net && params_host, "bz_net_update: null pointer");
+    return upload_params(net, params_host, (hipStream_t)stream);
+}
 
 #ifdef BZ_EXP_STAMPS
 BZ_EXPORT int32_t bz_debug_read(void* dst, int64_t bytes) {

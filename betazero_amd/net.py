@@ -101,6 +101,13 @@ class DeviceNet:
                           torch.cuda.current_stream().cuda_stream))
         return logits, value
 
+    def update(self, params):
+        """replace the weights in place (same architecture), e.g. after a training step"""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        assert params.size == _lib.lib().bz_net_param_count(self.C, self.NB, self.VH)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bz_net_update(self.h, params.ctypes.data, torch.cuda.current_stream().cuda_stream))
+
     def __del__(self):
         try:
             _lib.lib().bz_net_destroy(self.h)

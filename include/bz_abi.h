@@ -99,6 +99,16 @@ int32_t bz_ttt_step_batch(const uint16_t* own, const uint16_t* opp, const uint8_
                           const int8_t* to_move, int64_t n, uint16_t* own_next, uint16_t* opp_next,
                           uint16_t* legal_next, uint8_t* status, int8_t* winner, void* stream);
 
+/* 8-fold symmetry augmentation of (s, pi) rows on the device -- the transforms of
+ * TicTacToeDataset.expand_with_transforms, src/tic_tac_toe/SL/train.py:27-36, in the
+ * reference's order (id, flip rows, flip cols, rot90 x1/x2/x3, transpose, flip-rows-then-
+ * transpose; the last equals rot90 x3 under torch semantics, as in the reference).
+ * Row 8*i+t of the outputs = transform t of input row i; pi is permuted with the board
+ * (entries beyond size*size -- Reversi's pass -- stay).  key8 (optional, may be null) gets a
+ * 64-bit content key of each output row for the dedupe of train.py:45-50. */
+int32_t bz_augment_d4_batch(const uint64_t* own, const uint64_t* opp, const float* pi, int64_t n, int32_t size,
+                            int32_t na, uint64_t* own8, uint64_t* opp8, float* pi8, uint64_t* key8, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* Policy/value net (build-authored architecture, SURVEY.md 8(d) "net";      */
 /* the calling convention generalises AIPlayer.get_move players.py:84-98:    */
@@ -116,6 +126,8 @@ int64_t bz_net_workspace_bytes(int32_t C, int32_t NB, int32_t VH, int32_t max_ba
 int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_batch, const float* params_host,
                       void* workspace, int64_t workspace_bytes, void* stream, bz_net** out);
 int32_t bz_net_destroy(bz_net* net);
+/* replace the weights of an existing net (same shape) -- after a training step */
+int32_t bz_net_update(bz_net* net, const float* params_host, void* stream);
 /* own/opp: device u64[n]; logits: device f32[n][65]; value: device f32[n].
  * _f32: exact parity mode (k-ordered fmaf chains == oracle bit for bit).
  * _bf16: MFMA path (bf16 activations/weights, fp32 accumulate); needs C==128. */

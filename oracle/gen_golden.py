@@ -501,11 +501,52 @@ def gen_f7():
     print("F7", ci, "cases")
 
 
+# ---------------------------------------------------------------- F8: augmentation + CSV text
+def gen_f8():
+    """expand_with_transforms (SL/train.py:24-52) cannot be imported (train.py trains at import),
+    so its 8 torch expressions are applied here to the reference's own CSV rows: the expected
+    expanded + deduplicated dataset, in insertion order.  Also the CSV's checksum."""
+    import csv
+    import hashlib
+    import torch
+    transforms = [
+        lambda x: x, lambda x: x.flip(dims=[0]), lambda x: x.flip(dims=[1]), lambda x: x.rot90(1, [0, 1]),
+        lambda x: x.rot90(2, [0, 1]), lambda x: x.rot90(3, [0, 1]), lambda x: x.t(), lambda x: x.flip(dims=[0]).t(),
+    ]
+    path = os.path.join(REF, "tic_tac_toe_data.csv")
+    raw = open(path, "rb").read()
+    st, ac, src, tr = [], [], [], []
+    seen = set()
+    with open(path) as f:
+        rd = csv.reader(f)
+        next(rd)
+        for i, row in enumerate(rd):
+            s = torch.tensor([float(v) for v in row[0].split()]).view(3, 3)
+            a = torch.tensor([float(v) for v in row[1].split()]).view(3, 3)
+            for t, fn in enumerate(transforms):
+                ts, ta = fn(s), fn(a)
+                key = (",".join(map(str, ts.reshape(-1).tolist())), ",".join(map(str, ta.reshape(-1).tolist())))
+                if key not in seen:
+                    seen.add(key)
+                    st.append(ts.reshape(-1).to(torch.int64).tolist()); ac.append(ta.reshape(-1).to(torch.int64).tolist())
+                    src.append(i); tr.append(t)
+    # the 8 index maps on a 3x3 and an 8x8 grid (out.flat[i] = x.flat[map[i]])
+    maps3 = [fn(torch.arange(9).view(3, 3)).reshape(-1).tolist() for fn in transforms]
+    maps8 = [fn(torch.arange(64).view(8, 8)).reshape(-1).tolist() for fn in transforms]
+    np.savez_compressed(os.path.join(OUT, "augment.npz"), states=np.array(st, dtype=np.int64),
+                        actions=np.array(ac, dtype=np.int64), src=np.array(src), tr=np.array(tr),
+                        maps3=np.array(maps3), maps8=np.array(maps8))
+    with open(os.path.join(OUT, "csv_meta.json"), "w") as f:
+        json.dump({"sha256": hashlib.sha256(raw).hexdigest(), "bytes": len(raw), "rows": 180}, f)
+    print("F8", len(st), "augmented rows")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8"]
     if "f1" in which: gen_f1()
     if "f2" in which: gen_f2()
     if "f3" in which: gen_f3()
     if "f4" in which: gen_f4()
     if "f5" in which: gen_f5_f6()
     if "f7" in which: gen_f7()
+    if "f8" in which: gen_f8()

@@ -388,3 +388,65 @@ def test_cfg3_size_reversi_batch_properties():
         m = ex.game == g
         assert np.array_equal(ex.act[m], r["act"]) and np.array_equal(ex.pi[m].view(np.uint32), r["pi"].view(np.uint32))
     assert len(set(ex.act[ex.ply == 0].tolist())) > 1  # openings + tau=1 diversify the games
+
+
+# ---------------------------------------------------------------- SURVEY 8(f) rows
+def test_d4_augmentation_and_dedupe_match_the_reference_transforms():
+    """bz_augment_d4_batch + dedupe vs the reference's 8 torch transforms applied to its own CSV
+    (fixture augment.npz): same rows, same insertion order."""
+    from betazero_amd.augment import augment_examples
+    from betazero_amd.engine import Examples
+    d = np.load(os.path.join(G, "ttt_csv.npz"))
+    a = np.load(os.path.join(G, "augment.npz"))
+    st, ac = d["states"], d["actions"]
+    w = (1 << np.arange(9)).astype(np.uint64)
+    own = ((st == 1) * w).sum(1).astype(np.uint64)
+    opp = ((st == -1) * w).sum(1).astype(np.uint64)
+    ex = Examples(own, opp, ac.astype(np.float32), np.zeros(180, np.int8), np.ones(180, np.int8),
+                  ac.argmax(1).astype(np.uint8), np.arange(180) // 9, np.arange(180) % 9, 3)
+    full = augment_examples(ex, dedupe=False)
+    assert len(full) == 1440
+    for t in range(8):  # every transform equals the reference's index map
+        m = a["maps3"][t]
+        assert np.array_equal(full.states()[t::8].reshape(180, 9), st[:, m])
+        assert np.array_equal(full.pi[t::8], ac[:, m].astype(np.float32))
+    out = augment_examples(ex, dedupe=True)
+    assert len(out) == len(a["states"]) == 329
+    assert np.array_equal(out.states().reshape(-1, 9), a["states"])
+    assert np.array_equal(out.pi.astype(np.int64), a["actions"])
+    assert np.array_equal(out.act, a["actions"].argmax(1))
+    # 8x8 with the pass column: maps of the 8x8 grid, pass probability stays in column 64
+    rng = np.random.default_rng(2)
+    n = 50
+    o8 = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64)
+    p8 = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) & ~o8
+    pi8 = rng.random((n, 65)).astype(np.float32)
+    ex8 = Examples(o8, p8, pi8, np.zeros(n, np.int8), np.ones(n, np.int8), pi8[:, :64].argmax(1).astype(np.uint8),
+                   np.arange(n), np.zeros(n, np.int32), 8)
+    f8 = augment_examples(ex8, dedupe=False)
+    for t in range(8):
+        m = a["maps8"][t]
+        assert np.array_equal(f8.states()[t::8].reshape(n, 64), ex8.states().reshape(n, 64)[:, m])
+        assert np.array_equal(f8.pi[t::8, :64], pi8[:, m]) and np.array_equal(f8.pi[t::8, 64], pi8[:, 64])
+
+
+def test_training_step_closes_the_loop():
+    from betazero_amd.net import DeviceNet
+    from betazero_amd.train import make_optimizer, refresh_device_net, train_step
+    m = _net(128, 6, bf16=True)
+    dn = DeviceNet.from_module(m, 64)
+    eng = _engine("reversi", 32, 8, "net_bf16", net=dn, temp_moves=8, openings=1)
+    eng.run_iteration()
+    ex = eng.examples()
+    opt = make_optimizer(m, lr=1e-3)
+    losses = [train_step(m, opt, ex)[0] for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    own, opp = _dev_u64(ex.own[:16]), _dev_u64(ex.opp[:16])
+    before = dn.forward(own, opp)[0].cpu().numpy()
+    refresh_device_net(dn, m)
+    after = dn.forward(own, opp)[0].cpu().numpy()
+    assert np.abs(after - before).max() > 1e-4  # the engine's net now holds the trained weights
+    import copy
+    mm = copy.deepcopy(m).cpu().round_to_bf16_()
+    olg, _ = orc.Net(128, 6, 64, mm.flat_params()).forward(ex.own[:16], ex.opp[:16], bf16=True)
+    assert np.abs(after - olg).max() < 2e-2
