@@ -1,7 +1,8 @@
-# A/B of compile-time variants on ONE device: usage: exp_ab.sh "<flagsA>" "<flagsB>" [rounds]
+# A/B of compile-time variants on ONE device: usage: exp_ab.sh "<flagsA>" "<flagsB>"
 for i in 1 2; do
 for f in "$1" "$2"; do
   BZ_EXTRA_HIPCC_FLAGS="$f" python betazero_amd/build.py > /dev/null 2>&1 || echo BUILD FAIL
   echo "== [$f]"; python tools/bench_net.py 4096 150 | grep tower
+  if [ "$i" = "1" ]; then python -m pytest tests -m gpu -x -q -k "net_bf16 or bf16_net or training" 2>&1 | tail -1; fi
 done; done
 python betazero_amd/build.py > /dev/null 2>&1
