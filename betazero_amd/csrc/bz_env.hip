@@ -148,34 +148,69 @@ BZ_EXPORT int32_t bz_ttt_game_over(uint32_t x, uint32_t o, int32_t* over, int32_
 }
 
 // ---------------------------------------------------------------- kernels
+// one env step; a placement is legal iff the cell is empty and it flips something, so the
+// mover's full legal mask is only needed for the (rare) pass action
+__device__ __forceinline__ void reversi_step_one(u64 me, u64 you, int a, u64& cown, u64& copp, u64& nl, uint8_t& st,
+                                                 int8_t& w) {
+    cown = me; copp = you; st = BZ_ST_ILLEGAL; w = 0;
+    bool ok;
+    if (a == kPass) {
+        nl = rev_legal8(me, you);
+        ok = nl == 0;
+        if (ok) { cown = you; copp = me; }
+    } else {
+        u64 m = a < 64 ? 1ULL << a : 0ULL;
+        u64 f = (m & ~(me | you)) ? rev_flips(me, you, m) : 0ULL;
+        ok = f != 0;
+        if (ok) { cown = you & ~f; copp = me | m | f; }
+        else nl = rev_legal8(me, you);
+    }
+    if (ok) {
+        nl = rev_legal8(cown, copp);
+        st = BZ_ST_RUNNING;
+        if (nl == 0) {
+            if (rev_legal8(copp, cown) == 0) {
+                st = BZ_ST_TERMINAL;
+                int d = popc64(copp) - popc64(cown);  // copp = the player who just moved
+                w = (int8_t)(d > 0 ? 1 : (d < 0 ? -1 : 0));
+            } else {
+                st = BZ_ST_MUST_PASS;
+            }
+        }
+    }
+}
+
+// 4 games per lane: 2 x 16-byte loads per bitboard array, 4-byte loads/stores of the byte arrays
 __global__ void __launch_bounds__(256) k_reversi_step(const u64* __restrict__ own, const u64* __restrict__ opp,
                                                       const uint8_t* __restrict__ action, int64_t n,
                                                       u64* __restrict__ own_next, u64* __restrict__ opp_next,
                                                       u64* __restrict__ legal_next, uint8_t* __restrict__ status,
                                                       int8_t* __restrict__ winner) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        u64 me = own[i], you = opp[i];
-        int a = action[i];
-        u64 lg = rev_legal8(me, you);
-        bool ok = a == kPass ? lg == 0 : (a < 64 && ((lg >> a) & 1ULL));
-        u64 cown = me, copp = you, nl = lg;
-        uint8_t st = BZ_ST_ILLEGAL;
-        int8_t w = 0;
-        if (ok) {
-            Reversi::apply(me, you, a, &cown, &copp);
-            nl = rev_legal8(cown, copp);
-            st = BZ_ST_RUNNING;
-            if (nl == 0) {
-                if (rev_legal8(copp, cown) == 0) {
-                    st = BZ_ST_TERMINAL;
-                    int d = popc64(copp) - popc64(cown);  // copp = the player who just moved
-                    w = d > 0 ? 1 : (d < 0 ? -1 : 0);
-                } else {
-                    st = BZ_ST_MUST_PASS;
-                }
-            }
-        }
-        own_next[i] = cown; opp_next[i] = copp; legal_next[i] = nl; status[i] = st; winner[i] = w;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const ulonglong2* o2 = reinterpret_cast<const ulonglong2*>(own) + 2 * i;
+        const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(opp) + 2 * i;
+        ulonglong2 oa = o2[0], ob = o2[1], pa = p2[0], pb = p2[1];
+        uchar4 ac = reinterpret_cast<const uchar4*>(action)[i];
+        u64 me[4] = {oa.x, oa.y, ob.x, ob.y}, you[4] = {pa.x, pa.y, pb.x, pb.y};
+        int aa[4] = {ac.x, ac.y, ac.z, ac.w};
+        u64 co[4], cp[4], nl[4]; uint8_t st[4]; int8_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reversi_step_one(me[k], you[k], aa[k], co[k], cp[k], nl[k], st[k], w[k]);
+        ulonglong2* on2 = reinterpret_cast<ulonglong2*>(own_next) + 2 * i;
+        ulonglong2* pn2 = reinterpret_cast<ulonglong2*>(opp_next) + 2 * i;
+        ulonglong2* ln2 = reinterpret_cast<ulonglong2*>(legal_next) + 2 * i;
+        on2[0] = make_ulonglong2(co[0], co[1]); on2[1] = make_ulonglong2(co[2], co[3]);
+        pn2[0] = make_ulonglong2(cp[0], cp[1]); pn2[1] = make_ulonglong2(cp[2], cp[3]);
+        ln2[0] = make_ulonglong2(nl[0], nl[1]); ln2[1] = make_ulonglong2(nl[2], nl[3]);
+        reinterpret_cast<uchar4*>(status)[i] = make_uchar4(st[0], st[1], st[2], st[3]);
+        reinterpret_cast<char4*>(winner)[i] = make_char4(w[0], w[1], w[2], w[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // ragged tail
+        int64_t i = (n4 << 2) + threadIdx.x;
+        u64 co, cp, nl; uint8_t st; int8_t w;
+        reversi_step_one(own[i], opp[i], action[i], co, cp, nl, st, w);
+        own_next[i] = co; opp_next[i] = cp; legal_next[i] = nl; status[i] = st; winner[i] = w;
     }
 }
 
@@ -275,8 +310,11 @@ BZ_EXPORT int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp
     BZ_REQUIRE(n >= 0 && own && opp && action && own_next && opp_next && legal_next && status && winner,
                "bz_reversi_step_batch: null pointer");
     if (n == 0) return BZ_OK;
+    BZ_REQUIRE((((uintptr_t)own | (uintptr_t)opp | (uintptr_t)own_next | (uintptr_t)opp_next | (uintptr_t)legal_next) & 15) == 0 &&
+                   (((uintptr_t)action | (uintptr_t)status | (uintptr_t)winner) & 3) == 0,
+               "bz_reversi_step_batch: arrays must be 16-byte (u64) / 4-byte (u8) aligned");
     ProfScope ps(BZ_PROF_ENV_STEP, stream);
-    hipLaunchKernelGGL(k_reversi_step, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, action, n,
+    hipLaunchKernelGGL(k_reversi_step, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, own, opp, action, n,
                        own_next, opp_next, legal_next, status, winner);
     BZ_LAUNCH_CHECK("k_reversi_step");
     return BZ_OK;

@@ -64,12 +64,12 @@ BZ_HD u64 rev_legal8(u64 own, u64 opp) { return rev_legal(own, opp, ~0ULL); }
 // stones flipped by placing on bit m (m must be a legal cell); the 8 rays of
 // make_move (reversi_board.py:49-58)
 BZ_HD u64 rev_flips_dir(u64 own, u64 o, u64 m, int s) {
+    // runs of <= 6 opponent stones next to m, parallel-prefix (2 + 2 + 2 cells)
     u64 fl = o & (m << s), fr = o & (m >> s);
-    fl |= o & (fl << s); fr |= o & (fr >> s);
-    fl |= o & (fl << s); fr |= o & (fr >> s);
-    fl |= o & (fl << s); fr |= o & (fr >> s);
-    fl |= o & (fl << s); fr |= o & (fr >> s);
-    fl |= o & (fl << s); fr |= o & (fr >> s);
+    fl |= o & (fl << s);      fr |= o & (fr >> s);
+    u64 pl = o & (o << s),    pr = o & (o >> s);
+    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
     u64 out = 0;
     if ((fl << s) & own) out |= fl;
     if ((fr >> s) & own) out |= fr;
