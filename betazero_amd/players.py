@@ -32,6 +32,40 @@ class ReversiRandomPlayer(ReversiPlayer):  # reversi_players.py:26-32
         return random.choice(moves) if moves else (None, None)
 
 
+class MinimaxPlayer(Player):
+    """Full-depth minimax for Tic-tac-toe over the Game API -- the strength yard-stick of
+    SURVEY 8(f) row 3.  Same decision rule as the reference's OptimalPlayer
+    (src/tic_tac_toe/players.py:30-70): random opening move on an empty board, otherwise the
+    first move with the best minimax score in generate_possible_moves() order."""
+
+    def __init__(self, symbol):
+        self.symbol = symbol
+        self._memo = {}
+
+    def get_move(self, board):
+        moves = board.generate_possible_moves()
+        if len(moves) == 9:
+            return random.choice(moves)
+        return self._minimax(board, True)[1]
+
+    def _minimax(self, board, is_max):
+        key = (board.board.tobytes(), is_max)
+        if key in self._memo:
+            return self._memo[key]
+        over, winner = board.is_game_over()
+        if over:
+            res = ((1 if winner == self.symbol else -1 if winner == -self.symbol else 0), None)
+        else:
+            best, best_move = (-2, None) if is_max else (2, None)
+            for mv in board.generate_possible_moves():
+                sc, _ = self._minimax(board.make_move(*mv, self.symbol if is_max else -self.symbol), not is_max)
+                if (is_max and sc > best) or (not is_max and sc < best):
+                    best, best_move = sc, mv
+            res = (best, best_move)
+        self._memo[key] = res
+        return res
+
+
 class MCTSPlayer(Player):
     """get_move(board) -> (row, col) by one GPU search (PUCT, `sims` simulations)
     from `board` with `symbol` to move; plays argmax visit count (ties -> lowest

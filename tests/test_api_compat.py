@@ -148,3 +148,12 @@ def test_reversi_headless_random_games_terminate_with_pass_rule():
         assert g.board.is_game_over() and winner in (-1, 0, 1)
         assert len(positions) == len(g.movers) + 1
     assert bz.ReversiRandomPlayer(1).get_move(bz.ReversiBoard.from_bits(0, 0, 8)) == (None, None)
+
+
+def test_minimax_yardstick_self_play_always_draws():
+    """like the reference's CSV (20 Optimal-vs-Optimal games, all drawn in 9 plies)"""
+    import random
+    random.seed(5)
+    for _ in range(5):
+        positions, winner = bz.TicTacToeHeadless(bz.MinimaxPlayer(1), bz.MinimaxPlayer(-1)).play()
+        assert winner == 0 and len(positions) == 10
