@@ -90,19 +90,21 @@ struct LogitSrc {
     }
 };
 
-// ---- cooperative tree walk: kGW = 16 lanes serve one game (4 games per wave).  A level of the
+// ---- cooperative tree walk: G::GW lanes serve one game (Reversi 16 -> 4 games per wave, TTT 8 -> 8
+// games per wave: the walk is a dependent chain per game, so games in flight = memory-level
+// parallelism).  A level of the
 // PUCT walk is one broadcast node load + one coalesced 256-byte load of up to 16 edges, the
 // scores are computed one child per lane and reduced with 4 shuffle steps (first maximum, i.e.
 // lowest action on ties); softmax terms are computed one legal move per lane, but SUMMED in
 // ascending action order by a serial shuffle scan so that the result is bit-identical to the
 // sequential spec; the backup updates one path edge per lane.
-constexpr int kGW = 16;
 
 // M2: PUCT walk from the root; creates the child node behind the chosen unexpanded edge (env step:
 // apply + legal + terminal).  All lanes of the group return the same values.
 template <class G>
 __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u32 sim_idx, u32& n_nodes_g,
                                            u32& leaf, int& kind, int& depth_out, float& tval, Cnt& c) {
+    constexpr int kGW = G::GW;
     Node* nodes = E.nodes + (size_t)g * E.ncap;
     Edge* edges = E.edges + (size_t)g * E.ecap;
     u32 node = 0, sumN = sim_idx;  // sum of the root's child visits == simulations done so far
@@ -185,6 +187,7 @@ __device__ __forceinline__ int nth_bit(u64 m, int k) {
 template <class G>
 __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal,
                                            const LogitSrc& ls, u32& n_edges_g, Cnt& c) {
+    constexpr int kGW = G::GW, kCH = (G::MAXCH + G::GW - 1) / G::GW;
     Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
     const u32 e0 = n_edges_g;
     Edge* ed = E.edges + (size_t)g * E.ecap + e0;
@@ -198,26 +201,26 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
     } else {
         n = popc64(legal);
         if (n > room) { if (sub == 0) atomicOr(&E.flags[FLAG_ERR], ERR_EDGE_OVERFLOW); n = room; }
-        // this lane's moves: the sub-th, (sub+16)-th and (sub+32)-th legal actions
-        int a[3]; float x[3];
+        // this lane's moves: the sub-th, (sub+GW)-th, ... legal actions
+        int a[kCH]; float x[kCH];
         float m = -__builtin_inff();
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < kCH; ++k) {
             a[k] = (sub + kGW * k < n) ? nth_bit(legal, sub + kGW * k) : -1;
             x[k] = a[k] >= 0 ? ls(a[k]) : -__builtin_inff();
             m = x[k] > m ? x[k] : m;
         }
 #pragma unroll
         for (int o = kGW / 2; o > 0; o >>= 1) { float m2 = __shfl_xor(m, o, kGW); m = m2 > m ? m2 : m; }
-        float ex[3];
+        float ex[kCH];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ex[k] = a[k] >= 0 ? expf_spec(x[k] - m) : 0.0f;
+        for (int k = 0; k < kCH; ++k) ex[k] = a[k] >= 0 ? expf_spec(x[k] - m) : 0.0f;
         float s = 0.0f;  // ascending-action serial sum (the spec's order), every lane computes it
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < kCH; ++k)
             for (int j = 0; j < kGW && kGW * k + j < n; ++j) s = s + __shfl(ex[k], j, kGW);
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < kCH; ++k)
             if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(ex[k], s); e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
     }
     if (sub == 0) {
@@ -230,6 +233,7 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
 }
 
 // M4: W is stored for the mover at the parent, so the sign flips every ply; one path edge per lane
+template <int kGW>
 __device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, Cnt& c) {
     Edge* edges = E.edges + (size_t)g * E.ecap;
     const int dmax = depth < E.maxd ? depth : E.maxd;
@@ -353,6 +357,7 @@ __global__ void __launch_bounds__(256) k_eval_synth(EngineDev E, int eval_kind) 
 // this kernel and the net.
 template <class G>
 __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, int do_select, u32 sim_idx) {
+    constexpr int kGW = G::GW;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
     Cnt c = {};
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
             } else {
                 v = (float)((int)((nd->info >> 9) & 3u) - 1);
             }
-            dev_backup(E, g, sub, (int)E.depth[g], v, c);
+            dev_backup<G::GW>(E, g, sub, (int)E.depth[g], v, c);
         }
         if (do_select) {
             uint8_t kind8 = LEAF_NONE;
@@ -406,6 +411,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
 // root expansion + sims x (select, expand, backup), no host round trip.
 template <class G>
 __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind) {
+    constexpr int kGW = G::GW;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
     Cnt c = {};
@@ -432,7 +438,7 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
                     dev_expand<G>(E, g, sub, leaf, G::legal(lo, lp), ls, ne, c);
                     v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
                 }
-                dev_backup(E, g, sub, depth, v, c);
+                dev_backup<G::GW>(E, g, sub, depth, v, c);
             }
             if (sub == 0) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
         }
@@ -578,7 +584,7 @@ Offsets carve(const bz_engine_cfg& c) {
     o.ex_len = k.take(R * B * 4); o.ex_winner = k.take(R * B);
     o.root_N = k.take(B * o.na * 4); o.root_W = k.take(B * o.na * 4); o.root_P = k.take(B * o.na * 4);
     o.counters = k.take(16 * 8);
-    o.n_cnt_slots = (int)((B * kGW + 63) / 64) + 4;  // one slot per wave of the widest (group) launch
+    o.n_cnt_slots = (int)((B * 16 + 63) / 64) + 4;  // one slot per wave of the widest (group) launch
     o.cnt_slots = k.take((int64_t)o.n_cnt_slots * CNT_N * 8);
     o.flags = k.take(FLAG_N * 4);
     o.total = k.off;
@@ -587,16 +593,16 @@ Offsets carve(const bz_engine_cfg& c) {
 
 template <class T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 inline dim3 grid_of(int B) { return dim3((B + 255) / 256); }
-inline dim3 grid_groups(int B) { return dim3(((size_t)B * kGW + 255) / 256); }
+inline dim3 grid_groups(int B, int gw) { return dim3(((size_t)B * gw + 255) / 256); }
 }  // namespace
 
 #define BZ_DISPATCH_G(e, KERNEL, stream, ...)                                                           \
     do {                                                                                                \
         if ((e)->cfg.game == BZ_GAME_TTT)                                                               \
-            hipLaunchKernelGGL(KERNEL<TicTacToe>, grid_groups((e)->dev.B), dim3(256), 0, (hipStream_t)(stream), \
+            hipLaunchKernelGGL(KERNEL<TicTacToe>, grid_groups((e)->dev.B, TicTacToe::GW), dim3(256), 0, (hipStream_t)(stream), \
                                __VA_ARGS__);                                                            \
         else                                                                                            \
-            hipLaunchKernelGGL(KERNEL<Reversi>, grid_groups((e)->dev.B), dim3(256), 0, (hipStream_t)(stream),   \
+            hipLaunchKernelGGL(KERNEL<Reversi>, grid_groups((e)->dev.B, Reversi::GW), dim3(256), 0, (hipStream_t)(stream),   \
                                __VA_ARGS__);                                                            \
         BZ_LAUNCH_CHECK(#KERNEL);                                                                       \
     } while (0)

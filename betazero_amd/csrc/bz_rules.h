@@ -97,6 +97,7 @@ BZ_HD bool ttt_over(u32 x, u32 o, int* winner) {
 // ---- game traits used by the tree / self-play kernels (8x8 Reversi, 3x3 TTT)
 struct Reversi {
     static constexpr int kGame = 1, NA = 65, MAXCH = 34, MAXD = 128;
+    static constexpr int GW = 16;  // lanes that serve one game in the tree kernels (mean branching 8.5, max 33)
     static BZ_HD u64 legal(u64 own, u64 opp) { return rev_legal8(own, opp); }
     // position after action a, seen by the next mover
     static BZ_HD void apply(u64 own, u64 opp, int a, u64* cown, u64* copp) {
@@ -120,6 +121,7 @@ struct Reversi {
 };
 struct TicTacToe {
     static constexpr int kGame = 0, NA = 9, MAXCH = 9, MAXD = 16;
+    static constexpr int GW = 4;   // 16 games per wave
     static BZ_HD u64 legal(u64 own, u64 opp) { return ~(own | opp) & 0x1FFULL; }
     static BZ_HD void apply(u64 own, u64 opp, int a, u64* cown, u64* copp) {
         *cown = opp;
