@@ -8,7 +8,7 @@ SO = os.path.join(HERE, "libbz_hip.so")
 
 BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
 GAME_TTT, GAME_REVERSI = 0, 1
-EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_EXTERNAL = range(5)
+EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_EXTERNAL, EVAL_NET_FP8 = range(6)
 ST_RUNNING, ST_TERMINAL, ST_ILLEGAL, ST_MUST_PASS = range(4)
 PASS_ACTION = 64
 PROF_SLOTS = ("tower", "stem", "heads", "select", "expand_backup", "search_fused", "play", "env_step")
@@ -53,6 +53,7 @@ _SIGS = {
     "bz_net_destroy": (i32, [vp]),
     "bz_net_forward_f32": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "bz_net_forward_bf16": (i32, [vp, vp, vp, i32, vp, vp, vp]),
+    "bz_net_forward_fp8": (i32, [vp, vp, vp, i32, vp, vp, vp]),
     "bz_engine_workspace_bytes": (i64, [C.POINTER(EngineCfg)]),
     "bz_engine_create": (i32, [C.POINTER(EngineCfg), vp, i64, C.POINTER(vp)]),
     "bz_engine_destroy": (i32, [vp]),

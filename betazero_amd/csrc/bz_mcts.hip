@@ -557,7 +557,7 @@ struct Offsets {
 
 bool cfg_ok(const bz_engine_cfg* c) {
     return c && (c->game == BZ_GAME_TTT || c->game == BZ_GAME_REVERSI) && c->n_games > 0 && c->sims >= 1 &&
-           c->sims < (1 << 20) && c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_EXTERNAL && c->rounds >= 1 &&
+           c->sims < (1 << 20) && c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_NET_FP8 && c->rounds >= 1 &&
            c->t_max >= 1;
 }
 
@@ -645,7 +645,8 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.depth = at<u32>(ws, o.depth); d.leaf_node = at<u32>(ws, o.leaf_node); d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
     d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
     d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp); d.leaf_slot = at<u32>(ws, o.leaf_slot);
-    d.compact = (cfg->eval_kind == BZ_EVAL_NET_F32 || cfg->eval_kind == BZ_EVAL_NET_BF16) ? 1 : 0;
+    d.compact = (cfg->eval_kind == BZ_EVAL_NET_F32 || cfg->eval_kind == BZ_EVAL_NET_BF16 ||
+                 cfg->eval_kind == BZ_EVAL_NET_FP8) ? 1 : 0;
     d.logits = at<float>(ws, o.logits); d.value = at<float>(ws, o.value);
     d.ex_own = at<u64>(ws, o.ex_own); d.ex_opp = at<u64>(ws, o.ex_opp); d.ex_pi = at<float>(ws, o.ex_pi);
     d.ex_z = at<int8_t>(ws, o.ex_z); d.ex_mover = at<int8_t>(ws, o.ex_mover); d.ex_act = at<uint8_t>(ws, o.ex_act);
@@ -737,7 +738,7 @@ BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
     BZ_REQUIRE(e->net, "bz_engine_evaluate: eval_kind needs a net (bz_engine_set_net)");
     BZ_REQUIRE(e->cfg.game == BZ_GAME_REVERSI, "bz_engine_evaluate: the conv net is 8x8 Reversi only");
     // leaves were packed by select: evaluate only the first flags[NEVAL] slots (device-side count)
-    return bz_net_forward_dev(e->net, ek == BZ_EVAL_NET_BF16, e->dev.c_own, e->dev.c_opp, e->dev.B,
+    return bz_net_forward_dev(e->net, ek == BZ_EVAL_NET_BF16 ? 1 : (ek == BZ_EVAL_NET_FP8 ? 2 : 0), e->dev.c_own, e->dev.c_opp, e->dev.B,
                               e->dev.flags + FLAG_NEVAL + e->pack_parity, e->dev.logits, e->dev.value, stream);
 }
 

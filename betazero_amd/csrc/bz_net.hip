@@ -42,6 +42,8 @@ struct bz_net {
     __bf16* conv_wf;                 // [2NB+pad][9][8][4][64][8] fragment-major (C == 128)
     __bf16 *stem_wf, *head_wf;       // [2][4][64][8], [8][64][8] fragments (C == 128)
     __bf16 *conv_wf16, *stem_wf16, *head_wf16;  // 16x16x32 shape: [L*9+1][4][8][64][8], [8][64][8], [4][64][8]
+    uint8_t *conv_wf8, *head_wf8;    // e4m3: [L*9+1][2][4][2][64][16], [2][2][64][16]
+    float *dq8, *head_dq8, *ones;    // [L][128], [4], [128]
     float *pol_w, *pol_b, *polfc_wT, *polfc_b;  // [2][C], [2], [128][65], [65]
     float *val_w, *val_b, *v1_wT, *v1_b, *v2_w, *v2_b;  // [C], [1], [64][VH], [VH], [VH], [1]
     // activations (device)
@@ -405,6 +407,8 @@ struct TowerArgs {
     const float* stem_b;             // [128]
     const uint4* head_wf;            // [8][64] fragments: rows 0,1 = policy conv1x1, row 2 = value conv1x1
     const uint4 *wf16, *stem_wf16, *head_wf16;  // the same three for the 16x16x32 MFMA shape
+    const uint4 *wf8, *head_wf8;     // fp8 (e4m3) fragments for the MX-scaled 32x32x64 MFMA
+    const float *dq8, *head_dq8, *ones;  // [n_layers][128] dequant factors 1/(s_w*16), [4], [128] x 1.0f
     const float *pol_b, *val_b;      // [2], [1]
     const float *polfc_wT, *polfc_b; // [128][65], [65]
     const float *v1_wT, *v1_b, *v2_w, *v2_b;  // [64][VH], [VH], [VH], [1]
@@ -793,13 +797,276 @@ __global__ void __launch_bounds__(256, 1) k_tower16_bf16(TowerArgs T) {
 }
 }  // namespace t16
 
+// ====================================================================================
+// fp8 variant (BASELINE config 5): same decomposition, tower on
+// v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, unit block scales: 2x the bf16 MFMA rate per
+// clock, half the operand bytes).  Operand map verified on hardware with
+// tools/probe/probe_mfma_fp8.hip: A lane l = row l&31, B lane l = col l&31, byte j of lane half h
+// pairs with byte j of half h (we define k = 32h + j); D as for bf16.  Quantisation spec
+// (betazero_amd/quant.py, oracle mode 2): weights e4m3(w * s_co) with a per-output-channel
+// power-of-two scale, activations stored as e4m3(x * 16); the epilogue multiplies the fp32
+// accumulator by 1/(s_co * 16), adds bias (+ skip / 16), ReLUs, clamps to 448/16 and converts.
+// LDS image: cell = 128 B (8 chunks of 16 B), chunk c of cell (y, x) at slot c ^ sw,
+// sw = (x>>1) | (y&1)<<2; a 256-B bank row holds two cells (x parity), so the 16 lanes of a
+// ds_read_b128 group hit 16 distinct slots; the halo lanes read a 256-B zero region.
+// ====================================================================================
+namespace f8 {
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int kZero = 64 * 128;
+constexpr int kTile = kZero + 256;  // 8,448
+constexpr int kBuf = 4 * kTile;     // 33,792
+constexpr int kLds = 2 * kBuf;      // 67,584
+constexpr float kActScale = 16.0f;
+constexpr int kUnit = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
+
+__device__ __forceinline__ int cell_base(int yy, int xx, int h) {  // chunk 2h of the cell; caller XORs (ks << 6) / 16
+    const bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
+    const int xv = xx & 7;
+    const int sw = ((xv >> 1) & 3) | ((yy & 1) << 2);
+    const int base = inb ? (yy * 8 + xx) * 128 : kZero + (xv & 1) * 128;
+    return base + (((2 * h) ^ sw) << 4);
+}
+__device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int cell = 32 * nt + r;
+        boff[nt] = cell_base((cell >> 3) + dy, (cell & 7) + dx, h);
+    }
+}
+__device__ __forceinline__ v8i ld32(const char* p0, int off) {
+    v4i lo = *reinterpret_cast<const v4i*>(p0 + off);
+    v4i hi = *reinterpret_cast<const v4i*>(p0 + (off ^ 16));
+    v8i v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return v;
+}
+// activation fragments of one half-step: positions 2*pp, 2*pp+1 x 2 cell tiles
+__device__ __forceinline__ void load_b(v8i (&b)[2][2], const char* in, const int (&boff)[2], int ks, int pp) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[q][nt] = ld32(in + (2 * pp + q) * kTile, boff[nt] ^ (ks << 6));
+}
+__device__ __forceinline__ void mfma4(f32x16 (&acc)[4][2], const v8i& a, const v8i (&b)[2][2], int pp) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            acc[2 * pp + q][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[q][nt], acc[2 * pp + q][nt], 0, 0, 0,
+                                                                               kUnit, 0, kUnit);
+}
+
+template <int S>
+__device__ __forceinline__ void tap_step(f32x16 (&acc)[4][2], v8i (&A0)[2], v8i (&A1)[2], const uint4*& ap, const char* in,
+                                         int (&boff)[2], int next_tap, int r, int h, v8i (&b0)[2][2], v8i (&b1)[2][2]) {
+    v8i (&use)[2] = S ? A1 : A0;
+    v8i (&nxt)[2] = S ? A0 : A1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 lo = ap[(size_t)((ks * 4) * 2 + 0) * 64], hi = ap[(size_t)((ks * 4) * 2 + 1) * 64];
+        v8i v = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        nxt[ks] = v;
+    }
+    ap += 2 * 4 * 2 * 64;
+    int boff_n[2];
+    tap_off(next_tap, r, h, boff_n);
+    load_b(b1, in, boff, 0, 1);
+    mfma4(acc, use[0], b0, 0);
+    load_b(b0, in, boff, 1, 0);
+    mfma4(acc, use[0], b1, 1);
+    load_b(b1, in, boff, 1, 1);
+    mfma4(acc, use[1], b0, 0);
+    load_b(b0, in, boff_n, 0, 0);  // first half-step of the next tap
+    mfma4(acc, use[1], b1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+    }
+    boff[0] = boff_n[0]; boff[1] = boff_n[1];
+}
+
+// acc * dq + bias (+ skip) -> ReLU -> e4m3(x * 16) -> LDS; lane (r, h) register 4q+i = channel 32w+8q+4h+i
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], char* out, bool second, const float* __restrict__ dq,
+                                         const float* __restrict__ bl, int w, int r, int h) {
+    f32x4 dqv[4], bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        dqv[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q);
+        bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int cell = 32 * nt + r, y = cell >> 3, x = cell & 7;
+        const int sw = ((x >> 1) & 3) | ((y & 1) << 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int chunk = 2 * w + (q >> 1);
+            const int base = cell * 128 + ((chunk ^ sw) << 4) + 8 * (q & 1) + 4 * h;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int off = p * kTile + base;
+                f32x4 v = {acc[p][nt][4 * q], acc[p][nt][4 * q + 1], acc[p][nt][4 * q + 2], acc[p][nt][4 * q + 3]};
+                v = v * dqv[q] + bq[q];
+                if (second) {
+                    int sk = *reinterpret_cast<const int*>(out + off);
+                    f32x4 s4 = {__builtin_amdgcn_cvt_f32_fp8(sk, 0), __builtin_amdgcn_cvt_f32_fp8(sk, 1),
+                                __builtin_amdgcn_cvt_f32_fp8(sk, 2), __builtin_amdgcn_cvt_f32_fp8(sk, 3)};
+                    v = v + s4 * (1.0f / kActScale);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = v[i] > 0.0f ? v[i] : 0.0f;
+                    t = t * kActScale;
+                    v[i] = t < 448.0f ? t : 448.0f;
+                }
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                *reinterpret_cast<int*>(out + off) = pk;
+            }
+        }
+    }
+}
+
+template <int S0>
+__device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ dq,
+                                           const float* __restrict__ bl, v8i (&A0)[2], v8i (&A1)[2], const uint4*& ap,
+                                           int w, int r, int h) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { acc[p][0] = (f32x16)(0.0f); acc[p][1] = (f32x16)(0.0f); }
+    int boff[2];
+    tap_off(0, r, h, boff);
+    v8i b0[2][2], b1[2][2];
+    load_b(b0, in, boff, 0, 0);
+#pragma unroll 1
+    for (int t = 0; t < 8; t += 2) {
+        tap_step<S0>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
+        tap_step<1 - S0>(acc, A0, A1, ap, in, boff, t + 2, r, h, b0, b1);
+    }
+    tap_step<S0>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);
+    epilogue(acc, out, second, dq, bl, w, r, h);
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256, 1) k_tower_fp8(TowerArgs T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pos0 = blockIdx.x * 4;
+    if (T.n_dev) T.n = (int)*T.n_dev;
+    if (pos0 >= T.n) return;
+    char* bufX = smem;
+    char* bufM = smem + kBuf;
+    const int r = lane & 31, h = lane >> 5;
+
+    if (tid < 128) {  // zero regions: 2 buffers x 4 positions x 256 B
+        int k = tid & 15, p = (tid >> 4) & 3, b = tid >> 6;
+        *reinterpret_cast<uint4*>(smem + b * kBuf + p * kTile + kZero + k * 16) = make_uint4(0, 0, 0, 0);
+    }
+    // weight stream: tap t, k-step ks, co-tile w, 16-byte halves: wf8[(((t*2 + ks)*4 + w)*2 + half)*64 + lane]
+    const uint4* ap = T.wf8 + (size_t)(w * 2) * 64 + lane;
+    v8i A0[2], A1[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 lo = ap[(size_t)((ks * 4) * 2 + 0) * 64], hi = ap[(size_t)((ks * 4) * 2 + 1) * 64];
+        v8i v = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+        A0[ks] = v;
+    }
+    ap += 2 * 4 * 2 * 64;
+
+    // ---- stem (bf16 MFMA, exact 0/1 inputs) -> e4m3 activations
+    {
+        f32x16 acc[4][2];
+        bf16x8 sa[2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) sa[kc] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + w) * 64 + lane]);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int pos = pos0 + p < T.n ? pos0 + p : T.n - 1;
+            u64 own = T.own[pos], opp = T.opp[pos];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[p][nt] = (f32x16)(0.0f);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+                    acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc], stem_frag(own, opp, 32 * nt + r, 16 * kc + 8 * h),
+                                                                        acc[p][nt], 0, 0, 0);
+            }
+        }
+        epilogue(acc, bufX, false, T.ones, T.stem_b, w, r, h);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int blk = 0; blk < T.n_layers / 2; ++blk) {
+        conv_layer<0>(bufX, bufM, false, T.dq8 + (size_t)(2 * blk) * kTC, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h);
+        conv_layer<1>(bufM, bufX, true, T.dq8 + (size_t)(2 * blk + 1) * kTC, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w,
+                      r, h);
+    }
+
+    // ---- heads: wave p serves position p (conv1x1 in fp8, FCs in fp32)
+    if (pos0 + w < T.n) {
+        const int p = w, pos = pos0 + w;
+        float* S = reinterpret_cast<float*>(bufM + p * 1024);
+        const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
+        const float d0 = T.head_dq8[0], d1 = T.head_dq8[1], d2 = T.head_dq8[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16 acc = (f32x16)(0.0f);
+            const int cell = 32 * nt + r;
+            const int cb = cell_base(cell >> 3, cell & 7, h);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 lo = T.head_wf8[(ks * 2 + 0) * 64 + lane], hi = T.head_wf8[(ks * 2 + 1) * 64 + lane];
+                v8i a = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                v8i b = ld32(bufX + p * kTile, cb ^ (ks << 6));
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, kUnit, 0, kUnit);
+            }
+            if (h == 0) {
+                float a0 = acc[0] * d0 + pb0, a1 = acc[1] * d1 + pb1, a2 = acc[2] * d2 + vb;
+                S[cell] = a0 > 0.0f ? a0 : 0.0f;
+                S[64 + cell] = a1 > 0.0f ? a1 : 0.0f;
+                S[128 + cell] = a2 > 0.0f ? a2 : 0.0f;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        float acc = T.polfc_b[lane], part = 0.0f;
+#pragma unroll 4
+        for (int i = 0; i < 128; i += 4) {
+            f32x4 s4 = *reinterpret_cast<const f32x4*>(S + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(s4[j], T.polfc_wT[(i + j) * 65 + lane], acc);
+        }
+        part = S[lane] * T.polfc_wT[lane * 65 + 64] + S[lane + 64] * T.polfc_wT[(lane + 64) * 65 + 64];
+        part = wave_sum(part);
+        T.logits[(size_t)pos * 65 + lane] = acc;
+        if (lane == 0) T.logits[(size_t)pos * 65 + 64] = part + T.polfc_b[64];
+        float vh = 0.0f;
+        if (lane < T.VH) {
+            float a = T.v1_b[lane];
+#pragma unroll 4
+            for (int i = 0; i < 64; ++i) a = __builtin_fmaf(S[128 + i], T.v1_wT[i * T.VH + lane], a);
+            vh = (a > 0.0f ? a : 0.0f) * T.v2_w[lane];
+        }
+        vh = wave_sum(vh);
+        if (lane == 0) T.value[pos] = tanhf_spec(vh + T.v2_b[0]);
+    }
+}
+}  // namespace f8
+
 // ------------------------------------------------------------------ host helpers
 struct Carver {
     int64_t off = 0;
     int64_t take(int64_t bytes) { int64_t o = off; off += (bytes + 255) & ~int64_t(255); return o; }
 };
 struct NetOffsets {
-    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf16, stem_wf16, head_wf16, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
+    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf16, stem_wf16, head_wf16, conv_wf8, head_wf8, dq8, head_dq8, ones, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
         v2_b, act_a, act_b, act_h, total;
 };
 NetOffsets net_carve(int C, int NB, int VH, int mb) {
@@ -812,6 +1079,8 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     o.stem_wf = k.take(2 * 4 * 64 * 16); o.head_wf = k.take(8 * 64 * 16);
     o.conv_wf16 = k.take(C == kTC ? (L * 9 + 1) * 4LL * 8 * 64 * 16 : 0);
     o.stem_wf16 = k.take(8 * 64 * 16); o.head_wf16 = k.take(4 * 64 * 16);
+    o.conv_wf8 = k.take(C == kTC ? (L * 9 + 1) * 2LL * 4 * 2 * 64 * 16 : 0); o.head_wf8 = k.take(2 * 2 * 64 * 16);
+    o.dq8 = k.take((L + 1) * 128 * 4); o.head_dq8 = k.take(16); o.ones = k.take(128 * 4);
     o.pol_w = k.take(2LL * C * 4); o.pol_b = k.take(8); o.polfc_wT = k.take(128 * 65 * 4); o.polfc_b = k.take(65 * 4);
     o.val_w = k.take(C * 4LL); o.val_b = k.take(4); o.v1_wT = k.take(64LL * VH * 4); o.v1_b = k.take(VH * 4LL);
     o.v2_w = k.take(VH * 4LL); o.v2_b = k.take(4);
@@ -827,6 +1096,32 @@ uint16_t f2bf(float f) {
     __builtin_memcpy(&u, &f, 4);
     if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+// OCP e4m3fn encode (RNE, saturating at 448)
+uint8_t f2e4m3(float f) {
+    uint8_t sign = f < 0.0f ? 0x80 : 0;
+    float a = fabsf(f);
+    if (!(a == a)) return 0x7F;
+    if (a > 448.0f) a = 448.0f;
+    if (a == 0.0f) return sign;
+    int ex;
+    (void)frexpf(a, &ex);
+    int e = ex - 1 < -6 ? -6 : ex - 1;
+    float q = nearbyintf(a / ldexpf(1.0f, e - 3)) * ldexpf(1.0f, e - 3);
+    if (q > 448.0f) q = 448.0f;
+    if (q == 0.0f) return sign;
+    (void)frexpf(q, &ex);
+    int e2 = ex - 1;
+    if (e2 < -6) return sign | (uint8_t)nearbyintf(q * 512.0f);  // subnormal: mantissa * 2^-9
+    int mant = (int)nearbyintf((q / ldexpf(1.0f, e2) - 1.0f) * 8.0f);
+    return sign | (uint8_t)(((e2 + 7) << 3) | mant);
+}
+// largest power of two s with max|w| * s <= 448
+float pow2_scale(float maxabs) {
+    if (!(maxabs > 0.0f)) return 1.0f;
+    int ex;
+    (void)frexpf(448.0f / maxabs, &ex);
+    return ldexpf(1.0f, ex - 1);
 }
 template <class T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 }  // namespace
@@ -891,6 +1186,26 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
         for (int i = 0; i < C; ++i) F(o.conv_b)[(size_t)l * C + i] = q[i];
         q += C;
     }
+    if (C == kTC) {  // fp8 fragments + per-output-channel dequant factors, from the repacked fp32 weights
+        uint8_t* w8 = reinterpret_cast<uint8_t*>(img.data() + o.conv_wf8);
+        for (int l = 0; l < L; ++l) {
+            const float* wl = F(o.conv_w) + (size_t)l * 9 * C * C;  // [t][ci][co]
+            for (int co = 0; co < C; ++co) {
+                float mx = 0.0f;
+                for (int t = 0; t < 9; ++t)
+                    for (int ci = 0; ci < C; ++ci) mx = fmaxf(mx, fabsf(wl[((size_t)t * C + ci) * C + co]));
+                const float sc = pow2_scale(mx);
+                F(o.dq8)[(size_t)l * C + co] = 1.0f / (sc * 16.0f);
+                for (int t = 0; t < 9; ++t)
+                    for (int ci = 0; ci < C; ++ci) {
+                        int ks = ci >> 6, hh = (ci >> 5) & 1, j = ci & 31, half = j >> 4, mt = co >> 5, rr = co & 31;
+                        size_t f = ((((((size_t)l * 9 + t) * 2 + ks) * 4 + mt) * 2 + half) * 64 + (hh * 32 + rr)) * 16 + (j & 15);
+                        w8[f] = f2e4m3(wl[((size_t)t * C + ci) * C + co] * sc);
+                    }
+            }
+        }
+        for (int i = 0; i < 128; ++i) F(o.ones)[i] = 1.0f;
+    }
     for (int i = 0; i < 2 * C; ++i) F(o.pol_w)[i] = q[i];
     q += 2 * C;
     F(o.pol_b)[0] = q[0]; F(o.pol_b)[1] = q[1]; q += 2;
@@ -918,6 +1233,21 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                     int row = ln & 31, k = 16 * kc + 8 * (ln >> 5) + j;
                     float v = row < 2 ? F(o.pol_w)[row * C + k] : (row == 2 ? F(o.val_w)[k] : 0.0f);
                     hf[((size_t)kc * 64 + ln) * 8 + j] = f2bf(v);
+                }
+        uint8_t* h8 = reinterpret_cast<uint8_t*>(img.data() + o.head_wf8);
+        float hs[3];
+        for (int row = 0; row < 3; ++row) {
+            float mx = 0.0f;
+            for (int k = 0; k < C; ++k) mx = fmaxf(mx, fabsf(row < 2 ? F(o.pol_w)[row * C + k] : F(o.val_w)[k]));
+            hs[row] = pow2_scale(mx);
+            F(o.head_dq8)[row] = 1.0f / (hs[row] * 16.0f);
+        }
+        for (int ks = 0; ks < 2; ++ks)
+            for (int ln = 0; ln < 64; ++ln)
+                for (int j = 0; j < 32; ++j) {
+                    int row = ln & 31, k = 64 * ks + 32 * (ln >> 5) + j;
+                    float v = row < 2 ? F(o.pol_w)[row * C + k] * hs[row] : (row == 2 ? F(o.val_w)[k] * hs[2] : 0.0f);
+                    h8[((size_t)(ks * 2 + (j >> 4)) * 64 + ln) * 16 + (j & 15)] = f2e4m3(v);
                 }
         uint16_t* hf16 = reinterpret_cast<uint16_t*>(img.data() + o.head_wf16);
         for (int ks = 0; ks < 4; ++ks)
@@ -963,6 +1293,8 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
     n->conv_wf16 = C == kTC ? at<__bf16>(ws, o.conv_wf16) : nullptr;
     n->stem_wf16 = at<__bf16>(ws, o.stem_wf16); n->head_wf16 = at<__bf16>(ws, o.head_wf16);
+    n->conv_wf8 = C == kTC ? at<uint8_t>(ws, o.conv_wf8) : nullptr; n->head_wf8 = at<uint8_t>(ws, o.head_wf8);
+    n->dq8 = at<float>(ws, o.dq8); n->head_dq8 = at<float>(ws, o.head_dq8); n->ones = at<float>(ws, o.ones);
     n->pol_w = at<float>(ws, o.pol_w); n->pol_b = at<float>(ws, o.pol_b);
     n->polfc_wT = at<float>(ws, o.polfc_wT); n->polfc_b = at<float>(ws, o.polfc_b);
     n->val_w = at<float>(ws, o.val_w); n->val_b = at<float>(ws, o.val_b);
@@ -980,6 +1312,9 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
         e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(t16::k_tower16_bf16),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, t16::kLds);
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower16_bf16)"); }
+        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(f8::k_tower_fp8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 f8::kLds);
+        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_fp8)"); }
     }
     *out = n;
     return BZ_OK;
@@ -1025,7 +1360,7 @@ static int32_t forward_f32(bz_net* n, const uint64_t* own, const uint64_t* opp, 
 }
 
 static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, const u32* n_dev,
-                            float* logits, float* value, void* stream) {
+                            float* logits, float* value, void* stream, bool fp8) {
     hipStream_t s = (hipStream_t)stream;
     TowerArgs T;
     T.own = own; T.opp = opp; T.n_dev = n_dev; T.n = cnt; T.n_layers = 2 * n->NB; T.VH = n->VH;
@@ -1034,10 +1369,14 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     T.head_wf = reinterpret_cast<const uint4*>(n->head_wf); T.pol_b = n->pol_b; T.val_b = n->val_b;
     T.wf16 = reinterpret_cast<const uint4*>(n->conv_wf16); T.stem_wf16 = reinterpret_cast<const uint4*>(n->stem_wf16);
     T.head_wf16 = reinterpret_cast<const uint4*>(n->head_wf16);
+    T.wf8 = reinterpret_cast<const uint4*>(n->conv_wf8); T.head_wf8 = reinterpret_cast<const uint4*>(n->head_wf8);
+    T.dq8 = n->dq8; T.head_dq8 = n->head_dq8; T.ones = n->ones;
     T.polfc_wT = n->polfc_wT; T.polfc_b = n->polfc_b; T.v1_wT = n->v1_wT; T.v1_b = n->v1_b; T.v2_w = n->v2_w;
     T.v2_b = n->v2_b; T.logits = logits; T.value = value;
     {
         ProfScope ps(BZ_PROF_TOWER, stream);
+        if (fp8) hipLaunchKernelGGL(f8::k_tower_fp8, dim3((cnt + 3) / 4), dim3(256), f8::kLds, s, T);
+        else
 #if BZ_TOWER_SHAPE == 16
         hipLaunchKernelGGL(t16::k_tower16_bf16, dim3((cnt + 3) / 4), dim3(256), t16::kLds, s, T);
 #else
@@ -1049,13 +1388,13 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     return BZ_OK;
 }
 
-int32_t bz_net_forward_dev(bz_net* n, int bf16, const uint64_t* own, const uint64_t* opp, int32_t max_n,
+int32_t bz_net_forward_dev(bz_net* n, int bf16 /* 0 f32, 1 bf16, 2 fp8 */, const uint64_t* own, const uint64_t* opp, int32_t max_n,
                            const uint32_t* n_dev, float* logits, float* value, void* stream) {
     BZ_REQUIRE(n && own && opp && logits && value, "bz_net_forward: null pointer");
     BZ_REQUIRE(!bf16 || n->C == kTC, "bz_net_forward_bf16: the MFMA tower is built for C == 128");
     BZ_REQUIRE(max_n >= 0 && max_n <= n->max_batch, "bz_net_forward: batch exceeds max_batch");
     if (max_n == 0) return BZ_OK;
-    return bf16 ? forward_bf16(n, own, opp, max_n, n_dev, logits, value, stream)
+    return bf16 ? forward_bf16(n, own, opp, max_n, n_dev, logits, value, stream, bf16 == 2)
                 : forward_f32(n, own, opp, max_n, n_dev, logits, value, stream);
 }
 
@@ -1066,4 +1405,8 @@ BZ_EXPORT int32_t bz_net_forward_f32(bz_net* n, const uint64_t* own, const uint6
 BZ_EXPORT int32_t bz_net_forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, float* logits,
                                       float* value, void* stream) {
     return bz_net_forward_dev(n, 1, own, opp, cnt, nullptr, logits, value, stream);
+}
+BZ_EXPORT int32_t bz_net_forward_fp8(bz_net* n, const uint64_t* own, const uint64_t* opp, int32_t cnt, float* logits,
+                                     float* value, void* stream) {
+    return bz_net_forward_dev(n, 2, own, opp, cnt, nullptr, logits, value, stream);
 }

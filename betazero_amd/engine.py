@@ -8,13 +8,13 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (EVAL_EXTERNAL, EVAL_HASH, EVAL_NET_BF16, EVAL_NET_F32, EVAL_UNIFORM, GAME_REVERSI, GAME_TTT,
+from ._lib import (EVAL_EXTERNAL, EVAL_HASH, EVAL_NET_BF16, EVAL_NET_F32, EVAL_NET_FP8, EVAL_UNIFORM, GAME_REVERSI, GAME_TTT,
                    EngineCfg, EngineLayout)
 
 _GAMES = {"ttt": GAME_TTT, "tic_tac_toe": GAME_TTT, "reversi": GAME_REVERSI, GAME_TTT: GAME_TTT,
           GAME_REVERSI: GAME_REVERSI}
 _EVALS = {"uniform": EVAL_UNIFORM, "hash": EVAL_HASH, "net_f32": EVAL_NET_F32, "net_bf16": EVAL_NET_BF16,
-          "external": EVAL_EXTERNAL}
+          "external": EVAL_EXTERNAL, "net_fp8": EVAL_NET_FP8}
 
 
 def _u64(t):

@@ -90,12 +90,12 @@ class DeviceNet:
     def from_module(cls, module, max_batch, device="cuda:0"):
         return cls(module.C, module.NB, module.VH, module.flat_params(), max_batch, device)
 
-    def forward(self, own, opp, bf16=True):
+    def forward(self, own, opp, bf16=True, fp8=False):
         """own/opp: uint64-as-int64 CUDA tensors [n] -> (logits [n,65] f32, value [n] f32)"""
         n = own.numel()
         logits = torch.empty((n, 65), dtype=torch.float32, device=self.device)
         value = torch.empty((n,), dtype=torch.float32, device=self.device)
-        fn = _lib.lib().bz_net_forward_bf16 if bf16 else _lib.lib().bz_net_forward_f32
+        fn = _lib.lib().bz_net_forward_fp8 if fp8 else (_lib.lib().bz_net_forward_bf16 if bf16 else _lib.lib().bz_net_forward_f32)
         with torch.cuda.device(self.device):
             _lib.check(fn(self.h, own.data_ptr(), opp.data_ptr(), n, logits.data_ptr(), value.data_ptr(),
                           torch.cuda.current_stream().cuda_stream))

@@ -41,7 +41,7 @@ enum { BZ_GAME_TTT = 0, BZ_GAME_REVERSI = 1 };
  * (tree-kernel parity runs), the conv net in exact-fp32 parity mode, the conv
  * net on bf16 MFMA (the product path), or caller-filled logits/value. */
 enum { BZ_EVAL_UNIFORM = 0, BZ_EVAL_HASH = 1, BZ_EVAL_NET_F32 = 2, BZ_EVAL_NET_BF16 = 3,
-       BZ_EVAL_EXTERNAL = 4 };
+       BZ_EVAL_EXTERNAL = 4, BZ_EVAL_NET_FP8 = 5 };
 #define BZ_PASS_ACTION 64
 
 int32_t bz_abi_version(void);
@@ -135,6 +135,11 @@ int32_t bz_net_forward_f32(bz_net* net, const uint64_t* own, const uint64_t* opp
                            float* logits, float* value, void* stream);
 int32_t bz_net_forward_bf16(bz_net* net, const uint64_t* own, const uint64_t* opp, int32_t n,
                             float* logits, float* value, void* stream);
+/* _fp8: e4m3 weights (per-output-channel power-of-two scale) and activations (x16) on the
+ * MX-scaled 32x32x64 MFMA (BASELINE config 5); pass parameters fake-quantised by
+ * betazero_amd/quant.py.  Needs C == 128. */
+int32_t bz_net_forward_fp8(bz_net* net, const uint64_t* own, const uint64_t* opp, int32_t n,
+                           float* logits, float* value, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Batched MCTS self-play engine.  The plug-in point it fills is             */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libbz_oracle.so")
 
 GAME_TTT, GAME_REVERSI = 0, 1
-EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16 = 0, 1, 2, 3
+EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_NET_FP8 = 0, 1, 2, 3, 5
 PASS = 64
 COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",
                  "n_child_written", "n_env_steps", "n_net_leaves")
@@ -54,6 +54,8 @@ def lib():
         L.orc_ttt_apply.argtypes = [C.c_uint32, C.c_uint32, i32, i32, C.POINTER(C.c_uint32)]
         L.orc_expf.restype = C.c_float
         L.orc_expf.argtypes = [C.c_float]
+        L.orc_e4m3_round.restype = C.c_float
+        L.orc_e4m3_round.argtypes = [C.c_float]
         L.orc_tanhf.restype = C.c_float
         L.orc_tanhf.argtypes = [C.c_float]
         L.orc_eval_hash.restype = None
@@ -149,6 +151,7 @@ class Net:
         self.C, self.NB, self.VH = C_, NB, VH
 
     def forward(self, own, opp, bf16=False):
+        """bf16: False/0 = fp32, True/1 = bf16 emulation, 2 = fp8 (e4m3) emulation"""
         own = np.ascontiguousarray(own, dtype=np.uint64)
         opp = np.ascontiguousarray(opp, dtype=np.uint64)
         n = own.size

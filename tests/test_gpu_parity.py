@@ -467,3 +467,31 @@ def test_arena_mcts_never_loses_to_minimax_at_tictactoe():
         _, winner = bz.TicTacToeHeadless(p1, p2).play()
         res.append(winner * m.symbol)
     assert min(res) >= 0, res
+
+
+def test_net_fp8_mfma_vs_oracle_fp8_emulation():
+    """fp8 tower (e4m3 weights with per-channel power-of-two scales, e4m3(x*16) activations,
+    MX-scaled 32x32x64 MFMA, fp32 accumulate) vs the oracle quantising at the same points.
+    Accumulation order differs, and one e4m3 ulp is 2^-3 relative, so a handful of activations
+    land on the neighbouring code: tolerance 0.04 abs on logits / 0.02 on value (measured 0.009 / 0.002) (fp8 run is
+    BASELINE cfg 5, not the headline path); the fp8-vs-fp32 gap is printed."""
+    from betazero_amd.net import DeviceNet
+    from betazero_amd.quant import fake_quantize_fp8_
+    m = fake_quantize_fp8_(_net(128, 6))
+    n = 41
+    own, opp = _positions(n, seed=5)
+    dn = DeviceNet.from_module(m, 64)
+    lg, v = dn.forward(_dev_u64(own), _dev_u64(opp), fp8=True)
+    on = orc.Net(128, 6, 64, m.flat_params())
+    olg, ov = on.forward(own, opp, bf16=2)
+    err_l = np.abs(lg.cpu().numpy() - olg).max()
+    err_v = np.abs(v.cpu().numpy() - ov).max()
+    flg, fv = on.forward(own, opp, bf16=0)
+    print("fp8 net max |dlogit|", err_l, "max |dv|", err_v, "| fp8-vs-fp32 (same fake-quantised weights): logits",
+          np.abs(lg.cpu().numpy() - flg).max(), "value", np.abs(v.cpu().numpy() - fv).max(),
+          "| logit std", flg.std())
+    assert err_l < 0.04 and err_v < 0.02
+    # self-play with the fp8 net in the loop is legal and terminates
+    eng = _engine("reversi", 8, 8, "net_fp8", net=dn, temp_moves=8, openings=1)
+    eng.run_iteration()
+    assert (eng.winners()[1][0] > 20).all()
