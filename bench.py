@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
+                    help="net precision; bf16 is the BASELINE config, fp8 (e4m3, cfg 5 kernel) is a supplementary line")
     ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
     args = ap.parse_args()
 
@@ -138,6 +140,9 @@ def main():
     if reversi:
         torch.manual_seed(0)
         mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
+        if args.precision == "fp8":
+            from betazero_amd.quant import fake_quantize_fp8_
+            fake_quantize_fp8_(mod)
         net = DeviceNet.from_module(mod, B, dev)
         rounds = 2 + (W + K) // 40
         # NS independent pipelines of B/NS games, each on its own HIP stream: the tree step of one
@@ -146,7 +151,7 @@ def main():
         assert B % NS == 0
         Bs = B // NS
         streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-        engs = [SelfPlayEngine("reversi", Bs, sims, "net_bf16", net, temp_moves=8, openings=1, seed=0, rounds=rounds,
+        engs = [SelfPlayEngine("reversi", Bs, sims, "net_" + args.precision, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
                                game_id_base=rank * B + i * Bs, game_id_stride=world * B, device=dev,
                                stagger=PLIES_PER_GAME) for i in range(NS)]
         eng = engs[0]
@@ -212,9 +217,8 @@ def main():
                "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "data": "synthetic"}
         if reversi:
-            out["dtype"] = "bf16"
-            out["config"] = {"workload": "reversi8x8_4096games_800sims_convnet6x128_bf16" if (B, sims) == (4096, 800)
-                             else f"reversi8x8_{B}games_{sims}sims_convnet6x128_bf16",
+            out["dtype"] = args.precision
+            out["config"] = {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{args.precision}",
                              "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8,
                              "openings": 12, "net": "stem + 6 residual blocks x 128 ch, random init seed 0",
                              "step": "one move for all concurrent games (steady-state pool, staggered starts)",
@@ -226,19 +230,22 @@ def main():
             pos_per_launch = cnt["n_net_leaves"] / max(launches, 1)
             flop_per_launch = pos_per_launch * NET_FLOP_PER_POS  # stem + tower + heads are ONE kernel
             ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS if args.precision == "bf16" else 2 * MFMA_PEAK_TFLOPS  # dense fp8 = 5 PF
             union_ms, sum_ms = _lib.profile_union_ms("tower")
             conc = sum_ms / union_ms if union_ms else 1.0
             chip = cnt["n_net_leaves"] * NET_FLOP_PER_POS * (timed / max(launches, 1)) / (union_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "k_tower_bf16 (stem + 12 conv3x3 + heads, fused)",
-                               "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None, "launches": launches,
+            out["roofline"] = {"bound": "mfma", "kernel": ("k_tower_bf16" if args.precision == "bf16" else "f8::k_tower_fp8") +
+                               " (stem + 12 conv3x3 + heads, fused)",
+                               "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None, "launches": launches,
                                "avg_launch_ms": avg_ms, "positions_per_launch": pos_per_launch,
                                "flop_per_launch": flop_per_launch,
                                # launches of the NS pipelines overlap on the chip: per-launch duration is
                                # shared time.  chip-level = flops of all launches / union of their intervals
                                "concurrent_launches": conc, "achieved_chip": chip,
-                               "frac_chip": chip / MFMA_PEAK_TFLOPS}
+                               "frac_chip": chip / peak}
             try:
+                assert args.precision == "bf16"
                 tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_tower_bf16"]
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes at 4096 positions per launch (profiles/r01_pmc_traffic.json)"
@@ -272,7 +279,7 @@ def main():
             out["sims_per_s"] = cnt["n_sims"] * world / dt
         out["counters"] = cnt
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_reversi(sims) if reversi else cpu_baseline_ttt(sims)
+            out["cpu_baseline"] = cpu_baseline_reversi(sims) if reversi else cpu_baseline_ttt(sims)  # bf16-emulating oracle
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
