@@ -243,7 +243,11 @@ def main():
                                # launches of the NS pipelines overlap on the chip: per-launch duration is
                                # shared time.  chip-level = flops of all launches / union of their intervals
                                "concurrent_launches": conc, "achieved_chip": chip,
-                               "frac_chip": chip / peak}
+                               "frac_chip": chip / peak,
+                               "note": "achieved/frac are per launch as specified (flops of one launch / its mean "
+                                       "duration); with --streams 2 two launches share the chip, so each launch's "
+                                       "duration is shared time: achieved_chip = flops of all launches / union of "
+                                       "their intervals is the chip-level rate (--streams 1 makes the two coincide)"}
             try:
                 assert args.precision == "bf16"
                 tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_tower_bf16"]
