@@ -47,8 +47,7 @@ struct bz_net {
     float *pol_w, *pol_b, *polfc_wT, *polfc_b;  // [2][C], [2], [128][65], [65]
     float *val_w, *val_b, *v1_wT, *v1_b, *v2_w, *v2_b;  // [C], [1], [64][VH], [VH], [VH], [1]
     // activations (device)
-    float *act_a, *act_b;            // f32 path: [max_batch][64][C] x 2
-    __bf16* act_h;                   // bf16 path: [max_batch][64][C]
+    float *act_a, *act_b;            // f32 parity path: [max_batch][64][C] x 2 (the MFMA paths keep activations in LDS)
     void* ws_base;
 };
 
@@ -891,14 +890,16 @@ __device__ __forceinline__ void tap_step(f32x16 (&acc)[4][2], v8i (&A0)[2], v8i 
     boff[0] = boff_n[0]; boff[1] = boff_n[1];
 }
 
-// acc * dq + bias (+ skip) -> ReLU -> e4m3(x * 16) -> LDS; lane (r, h) register 4q+i = channel 32w+8q+4h+i
+// e4m3(16 * relu(acc * dq + bias (+ skip))) -> LDS, computed in the x16 domain: fma(acc, 16 dq, 16 bias)
+// (+ the stored skip code, which already is 16 x), one v_med3 for ReLU + saturation, cvt_pk.
+// lane (r, h) register 4q+i = channel 32w + 8q + 4h + i
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], char* out, bool second, const float* __restrict__ dq,
                                          const float* __restrict__ bl, int w, int r, int h) {
     f32x4 dqv[4], bq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        dqv[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q);
-        bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q);
+        dqv[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q) * kActScale;
+        bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q) * kActScale;
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -911,20 +912,16 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], char* out, bool se
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int off = p * kTile + base;
-                f32x4 v = {acc[p][nt][4 * q], acc[p][nt][4 * q + 1], acc[p][nt][4 * q + 2], acc[p][nt][4 * q + 3]};
-                v = v * dqv[q] + bq[q];
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[p][nt][4 * q + i], dqv[q][i], bq[q][i]);
                 if (second) {
                     int sk = *reinterpret_cast<const int*>(out + off);
-                    f32x4 s4 = {__builtin_amdgcn_cvt_f32_fp8(sk, 0), __builtin_amdgcn_cvt_f32_fp8(sk, 1),
-                                __builtin_amdgcn_cvt_f32_fp8(sk, 2), __builtin_amdgcn_cvt_f32_fp8(sk, 3)};
-                    v = v + s4 * (1.0f / kActScale);
+                    v[0] += __builtin_amdgcn_cvt_f32_fp8(sk, 0); v[1] += __builtin_amdgcn_cvt_f32_fp8(sk, 1);
+                    v[2] += __builtin_amdgcn_cvt_f32_fp8(sk, 2); v[3] += __builtin_amdgcn_cvt_f32_fp8(sk, 3);
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float t = v[i] > 0.0f ? v[i] : 0.0f;
-                    t = t * kActScale;
-                    v[i] = t < 448.0f ? t : 448.0f;
-                }
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.0f, 448.0f);
                 int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
                 pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
                 *reinterpret_cast<int*>(out + off) = pk;
@@ -1070,7 +1067,7 @@ struct Carver {
 };
 struct NetOffsets {
     int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf16, stem_wf16, head_wf16, conv_wf8, head_wf8, dq8, head_dq8, ones, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
-        v2_b, act_a, act_b, act_h, total;
+        v2_b, act_a, act_b, total;
 };
 NetOffsets net_carve(int C, int NB, int VH, int mb) {
     NetOffsets o{};
@@ -1087,7 +1084,7 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     o.pol_w = k.take(2LL * C * 4); o.pol_b = k.take(8); o.polfc_wT = k.take(128 * 65 * 4); o.polfc_b = k.take(65 * 4);
     o.val_w = k.take(C * 4LL); o.val_b = k.take(4); o.v1_wT = k.take(64LL * VH * 4); o.v1_b = k.take(VH * 4LL);
     o.v2_w = k.take(VH * 4LL); o.v2_b = k.take(4);
-    o.act_a = k.take(mbp * 64 * C * 4); o.act_b = k.take(mbp * 64 * C * 4); o.act_h = k.take(mbp * 64 * C * 2);
+    o.act_a = k.take(mbp * 64 * C * 4); o.act_b = k.take(mbp * 64 * C * 4);
     o.total = k.off;
     return o;
 }
@@ -1303,7 +1300,7 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->val_w = at<float>(ws, o.val_w); n->val_b = at<float>(ws, o.val_b);
     n->v1_wT = at<float>(ws, o.v1_wT); n->v1_b = at<float>(ws, o.v1_b);
     n->v2_w = at<float>(ws, o.v2_w); n->v2_b = at<float>(ws, o.v2_b);
-    n->act_a = at<float>(ws, o.act_a); n->act_b = at<float>(ws, o.act_b); n->act_h = at<__bf16>(ws, o.act_h);
+    n->act_a = at<float>(ws, o.act_a); n->act_b = at<float>(ws, o.act_b);
 
     n->ws_base = ws;
     int32_t urc = upload_params(n, p, (hipStream_t)stream);
