@@ -192,7 +192,6 @@ constexpr int kTileBytes = 65 * 256;      // 64 cells x 256 B + one zero cell
 constexpr int kPosPerWG = BZ_TOWER_P;    // positions resident per workgroup (4: one WG per CU; 2: two WGs per CU)
 template <int P> constexpr int buf_bytes() { return P * kTileBytes; }
 template <int P> constexpr int tower_lds() { return 2 * P * kTileBytes; }
-constexpr int kFragsPerLayer = 9 * 8 * 4 * 64;  // 16-byte fragments per layer
 
 #ifdef BZ_EXP_STAMPS
 __device__ unsigned long long g_dbg[8 * 4096];
@@ -368,7 +367,7 @@ template <int S0, int P>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
                                            bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap, int w, int r, int h,
                                            unsigned long long (&tacc)[4]) {
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
     f32x16 acc[P][2];
 #pragma unroll
@@ -450,7 +449,7 @@ k_tower_bf16(TowerArgs T) {
     const int pos0 = blockIdx.x * P;
     if (T.n_dev) T.n = (int)*T.n_dev;
     if (pos0 >= T.n) return;  // block-uniform, before any barrier
-    unsigned long long tacc[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tr0 = 0, tr1 = 0;
+    [[maybe_unused]] unsigned long long tacc[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tr0 = 0, tr1 = 0;
     BZ_STAMP(tk0);
 #ifdef BZ_EXP_STAMPS
     tr0 = __builtin_amdgcn_s_memrealtime();
@@ -933,7 +932,9 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], char* out, bool se
 template <int S0>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ dq,
                                            const float* __restrict__ bl, v8i (&A0)[2], v8i (&A1)[2], const uint4*& ap,
-                                           int w, int r, int h) {
+                                           int w, int r, int h, unsigned long long (&tacc)[4]) {
+    [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    BZ_STAMP(t0);
     f32x16 acc[4][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) { acc[p][0] = (f32x16)(0.0f); acc[p][1] = (f32x16)(0.0f); }
@@ -947,8 +948,12 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
         tap_step<1 - S0>(acc, A0, A1, ap, in, boff, t + 2, r, h, b0, b1);
     }
     tap_step<S0>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);
+    BZ_STAMP(t1);
     epilogue(acc, out, second, dq, bl, w, r, h);
+    BZ_STAMP(t2);
     __syncthreads();
+    BZ_STAMP(t3);
+    tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
 }
 
 #ifndef BZ_FP8_WAVES_PER_SIMD
@@ -961,6 +966,11 @@ __global__ void __launch_bounds__(256, BZ_FP8_WAVES_PER_SIMD) k_tower_fp8(TowerA
     const int pos0 = blockIdx.x * 4;
     if (T.n_dev) T.n = (int)*T.n_dev;
     if (pos0 >= T.n) return;
+    [[maybe_unused]] unsigned long long tacc[4] = {0, 0, 0, 0}, tk0 = 0, tk1 = 0, tr0 = 0, tr1 = 0;
+    BZ_STAMP(tk0);
+#ifdef BZ_EXP_STAMPS
+    tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     char* bufX = smem;
     char* bufM = smem + kBuf;
     const int r = lane & 31, h = lane >> 5;
@@ -1005,11 +1015,12 @@ __global__ void __launch_bounds__(256, BZ_FP8_WAVES_PER_SIMD) k_tower_fp8(TowerA
 
 #pragma unroll 1
     for (int blk = 0; blk < T.n_layers / 2; ++blk) {
-        conv_layer<0>(bufX, bufM, false, T.dq8 + (size_t)(2 * blk) * kTC, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h);
+        conv_layer<0>(bufX, bufM, false, T.dq8 + (size_t)(2 * blk) * kTC, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h, tacc);
         conv_layer<1>(bufM, bufX, true, T.dq8 + (size_t)(2 * blk + 1) * kTC, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w,
-                      r, h);
+                      r, h, tacc);
     }
 
+    BZ_STAMP(tk1);
     // ---- heads: wave p serves position p (conv1x1 in fp8, FCs in fp32)
     if (pos0 + w < T.n) {
         const int p = w, pos = pos0 + w;
@@ -1057,6 +1068,14 @@ __global__ void __launch_bounds__(256, BZ_FP8_WAVES_PER_SIMD) k_tower_fp8(TowerA
         vh = wave_sum(vh);
         if (lane == 0) T.value[pos] = tanhf_spec(vh + T.v2_b[0]);
     }
+#ifdef BZ_EXP_STAMPS
+    unsigned long long tk2; BZ_STAMP(tk2);
+    tr1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long* d = g_dbg + blockIdx.x * 8;
+        d[0] = tacc[0]; d[1] = tacc[1]; d[2] = tacc[2]; d[3] = tk1 - tk0; d[4] = tk2 - tk0; d[5] = tr1 - tr0; d[6] = tk0; d[7] = tr0;
+    }
+#endif
 }
 }  // namespace f8
 

@@ -4,12 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from betazero_amd import _lib
 from betazero_amd.net import DeviceNet, PolicyValueNet
 B = 4096
+FP8 = os.environ.get('FP8') == '1'
 rng = np.random.default_rng(0)
 x = rng.integers(0, 2**63, size=B, dtype=np.int64); y = rng.integers(0, 2**63, size=B, dtype=np.int64)
 own = torch.as_tensor(x & ~y).cuda(); opp = torch.as_tensor(y & ~x).cuda()
 torch.manual_seed(0)
 net = DeviceNet.from_module(PolicyValueNet(128, 6, 64).round_to_bf16_(), B)
-for _ in range(20): net.forward(own, opp)
+for _ in range(20): net.forward(own, opp, fp8=FP8)
 torch.cuda.synchronize()
 L = C.CDLL(_lib.SO)
 nb = 1024 if os.environ.get("NB_WG") is None else int(os.environ["NB_WG"])
