@@ -495,3 +495,34 @@ def test_net_fp8_mfma_vs_oracle_fp8_emulation():
     eng = _engine("reversi", 8, 8, "net_fp8", net=dn, temp_moves=8, openings=1)
     eng.run_iteration()
     assert (eng.winners()[1][0] > 20).all()
+
+
+def test_step_batch_empty_and_ragged_sizes():
+    """n = 0 is a no-op; n not a multiple of the 4-games-per-lane vector width takes the tail path"""
+    d = np.load(os.path.join(G, "reversi_positions.npz"))
+    pos = d["pos"][d["pos"][:, 0] == 8]
+    L = _lib.lib()
+    assert L.bz_reversi_step_batch(1, 1, 1, 0, 1, 1, 1, 1, 1, 0) == 0
+    assert L.bz_reversi_step_batch(None, None, None, 5, None, None, None, None, None, 0) == _lib.BZ_EINVAL
+    for n in (1, 2, 3, 5, 7, 130):
+        own, opp, legal = pos[:n, 1].copy(), pos[:n, 2].copy(), pos[:n, 3]
+        act = np.array([(int(l) & -int(l)).bit_length() - 1 if l else 64 for l in legal], dtype=np.uint8)
+        on, pn, lg, st, w = _reversi_step(own, opp, act)
+        for i in range(n):
+            a = int(act[i])
+            exp = (int(own[i]), int(opp[i]), 0) if a == 64 else orc.reversi_apply(int(own[i]), int(opp[i]), 8, a >> 3, a & 7)
+            assert (int(pn[i]), int(on[i])) == (exp[0], exp[1]) and st[i] != _lib.ST_ILLEGAL
+            assert int(lg[i]) == orc.reversi_legal(exp[1], exp[0], 8)
+
+
+def test_engine_ragged_batch_sizes_match_oracle():
+    """B = 1, 3, 5 games: partial lane groups / partial waves / partial net tiles"""
+    from betazero_amd.net import DeviceNet
+    m = _net(128, 6, bf16=True)
+    dn = DeviceNet.from_module(m, 8)
+    for B in (1, 3, 5):
+        _check_selfplay("reversi", B, 10, "hash", 4, 1, 9, base=B)
+        _check_selfplay("ttt", B, 12, "hash", 2, 0, 1)
+        eng = _engine("reversi", B, 4, "net_bf16", net=dn, openings=1)
+        eng.run_iteration()
+        assert (eng.winners()[1][0] > 8).all()
