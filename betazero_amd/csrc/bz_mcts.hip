@@ -1,11 +1,14 @@
-// bz_mcts.hip -- batched MCTS self-play engine for gfx950 (DESIGN.md 3, 4).
+// bz_mcts.hip -- batched MCTS self-play engine for gfx950 (DESIGN.md 3, 4, 5).
 //
-// One game per lane.  Per game the tree is a bump-allocated AoS pair in HBM:
+// G::GW lanes serve one game (Reversi 16, TTT 4).  Per game the tree is a bump-allocated AoS
+// pair in HBM:
 //   Node 32 B {own, opp, legal, edge0, info}     nodes[g][sims+2]
 //   Edge 16 B {N, W, P, child|action<<24}        edges[g][(sims+2)*MAXCH]
-// so one dwordx4 load brings an edge's (N, W, P, child) and a backup is one
-// 8-byte read-modify-write.  Per-game scalars are SoA across games (coalesced
-// per wave); the select path is stored depth-major path[d][g] (coalesced).
+// so one dwordx4 load brings an edge's (N, W, P, child), a node's children are one coalesced
+// block, and a backup is one 8-byte read-modify-write.  Per-game scalars are SoA across games;
+// the select path is stored depth-major path[d][g].  A simulation is two launches: k_tree_step
+// ([expand + backup of the previous leaf] + [select of the next one]) and the evaluator; leaves
+// that need the net are packed through a double-buffered device-side counter.
 //
 // Float discipline: compiled with -ffp-contract=off; PUCT / softmax / backup use
 // the single-rounding operation order of the oracle (oracle/bz_oracle.c), so
