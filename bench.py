@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
                     help="net precision; bf16 is the BASELINE config, fp8 (e4m3, cfg 5 kernel) is a supplementary line")
+    ap.add_argument("--mode", default="steady", choices=["steady", "iteration"],
+                    help="reversi: steady = one move per step on a staggered pool (default); iteration = a step is a\n"
+                         "complete self-play iteration from the start position to the last finished game (cross-check)")
     ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
     args = ap.parse_args()
 
@@ -153,17 +156,30 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
         engs = [SelfPlayEngine("reversi", Bs, sims, "net_" + args.precision, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
                                game_id_base=rank * B + i * Bs, game_id_stride=world * B, device=dev,
-                               stagger=PLIES_PER_GAME) for i in range(NS)]
+                               stagger=PLIES_PER_GAME if args.mode == "steady" else 0) for i in range(NS)]
         eng = engs[0]
         for e in engs:
             e.reset_games()
         torch.cuda.synchronize()
 
         def step():
-            for e, st in zip(engs, streams):
+            if args.mode == "steady":
+                for e, st in zip(engs, streams):
+                    with torch.cuda.stream(st):
+                        e.search()
+                        e.play(True)
+                return
+            for e, st in zip(engs, streams):  # one whole iteration: every game from its opening to the end
                 with torch.cuda.stream(st):
-                    e.search()
-                    e.play(True)
+                    e.reset_games()
+            active = True
+            while active:
+                for e, st in zip(engs, streams):
+                    with torch.cuda.stream(st):
+                        e.search()
+                        e.play(False)
+                torch.cuda.synchronize()
+                active = any(e.status()[0] > 0 for e in engs)
     else:
         eng = SelfPlayEngine("ttt", B, sims, "uniform", game_id_base=rank * B, game_id_stride=world * B, device=dev)
         engs = [eng]
@@ -198,7 +214,7 @@ def main():
     dt = time.perf_counter() - t0
     L.bz_profile_enable(0)
     fin1 = sum(e.status()[1] for e in engs)
-    if not reversi:
+    if not reversi or args.mode == "iteration":
         fin1, fin0 = K * B, 0
     games = float(fin1 - fin0)
     if world > 1:
@@ -221,7 +237,8 @@ def main():
             out["config"] = {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{args.precision}",
                              "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8,
                              "openings": 12, "net": "stem + 6 residual blocks x 128 ch, random init seed 0",
-                             "step": "one move for all concurrent games (steady-state pool, staggered starts)",
+                             "step": "one move for all concurrent games (steady-state pool, staggered starts)"
+                             if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",
                              "pipelines": f"{NS} x {Bs} games on separate HIP streams",
                              "parallelism": f"games sharded over {n_gpus} GPU(s), one all-gather of examples"}
             launches, timed, ms = prof["tower"]
