@@ -526,3 +526,39 @@ def test_engine_ragged_batch_sizes_match_oracle():
         eng = _engine("reversi", B, 4, "net_bf16", net=dn, openings=1)
         eng.run_iteration()
         assert (eng.winners()[1][0] > 8).all()
+
+
+def test_search_wide_nodes_and_cpuct_variants_vs_oracle():
+    """positions with 17..28 legal moves (the >16-children chunk path of the 16-lane walk, arbitrary
+    unreachable stones included) and other exploration constants: root N/W/P bit-exact vs the oracle"""
+    rng = np.random.default_rng(3)
+    rows = []
+    while len(rows) < 40:  # seeded random stones, filtered by the oracle: 17..21 legal moves at the root
+        u = rng.random(64)
+        own_ = sum(1 << i for i in range(64) if u[i] < 0.12)
+        opp_ = sum(1 << i for i in range(64) if 0.12 <= u[i] < 0.52)
+        c = bin(orc.reversi_legal(own_, opp_)).count("1")
+        if c >= 17:
+            rows.append((own_, opp_, 1 if len(rows) % 2 == 0 else -1, c))
+    assert max(r[3] for r in rows) >= 19
+    own = np.array([r[0] for r in rows], dtype=np.uint64)
+    opp = np.array([r[1] for r in rows], dtype=np.uint64)
+    tm = np.array([r[2] for r in rows], dtype=np.int8)
+    for c_puct, sims in ((1.5, 300), (0.25, 150), (6.0, 150)):
+        eng = _engine("reversi", len(rows), sims, "hash", c_puct=c_puct)
+        eng.set_roots(own, opp, tm)
+        eng.search()
+        N, W, P = eng.root_stats()
+        eng.status()
+        for g in range(len(rows)):
+            n, w, p, _ = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(tm[g]), sims, orc.EVAL_HASH,
+                                         c_puct=c_puct)
+            assert np.array_equal(N[g], n), (g, c_puct)
+            assert np.array_equal(W[g].view(np.uint32), w.view(np.uint32))
+            assert np.array_equal(P[g].view(np.uint32), p.view(np.uint32))
+
+
+def test_selfplay_longer_searches_vs_oracle_bitexact():
+    _check_selfplay("reversi", 64, 100, "hash", 8, 1, 21, base=1000)
+    _check_selfplay("ttt", 256, 200, "hash", 9, 0, 4)      # 200 sims: the tree saturates into terminals
+    _check_selfplay("ttt", 64, 60, "uniform", 3, 0, 2, base=7)
