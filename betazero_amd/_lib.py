@@ -69,6 +69,9 @@ _SIGS = {
     "bz_engine_root_stats": (i32, [vp, vp]),
     "bz_engine_play": (i32, [vp, i32, vp]),
     "bz_engine_status": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
+    "bz_mcts_select": (i32, [vp, u32, vp]),
+    "bz_mcts_expand_backup": (i32, [vp, vp]),
+    "bz_selfplay_run": (i32, [vp, i32, vp]),
     "bz_engine_reset_counters": (i32, [vp, vp]),
     "bz_engine_sum_counters": (i32, [vp, vp]),
     "bz_profile_enable": (i32, [i32]),

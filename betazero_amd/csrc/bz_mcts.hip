@@ -798,3 +798,12 @@ BZ_EXPORT int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active
     return BZ_OK;
 }
 
+
+/* names used by SURVEY.md 8(b) for the same entry points */
+BZ_EXPORT int32_t bz_mcts_select(bz_engine* e, uint32_t sim_index, void* stream) { return bz_engine_select(e, sim_index, stream); }
+BZ_EXPORT int32_t bz_mcts_expand_backup(bz_engine* e, void* stream) { return bz_engine_expand_backup(e, stream); }
+/* one move for every active slot: search (root expansion + cfg.sims simulations) then play */
+BZ_EXPORT int32_t bz_selfplay_run(bz_engine* e, int32_t restart, void* stream) {
+    int32_t rc = bz_engine_search(e, stream);
+    return rc != BZ_OK ? rc : bz_engine_play(e, restart, stream);
+}

@@ -211,6 +211,11 @@ int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream);
 /* synchronises the stream; number of active slots / finished games so far */
 int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
                          int32_t* error_flags);
+/* aliases under the names SURVEY.md 8(b) lists: select / expand+backup of one simulation, and
+ * one whole move (search + play) for every active slot */
+int32_t bz_mcts_select(bz_engine* e, uint32_t sim_index, void* stream);
+int32_t bz_mcts_expand_backup(bz_engine* e, void* stream);
+int32_t bz_selfplay_run(bz_engine* e, int32_t restart, void* stream);
 int32_t bz_engine_reset_counters(bz_engine* e, void* stream);
 /* fold the kernels' per-wave counter slots into the layout's counters[16] array (async) */
 int32_t bz_engine_sum_counters(bz_engine* e, void* stream);
