@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libbz_oracle.so")
+_SO = os.environ.get("BZ_ORACLE_SO", os.path.join(_HERE, "libbz_oracle.so"))  # BZ_ORACLE_SO: e.g. the ASan build
 
 GAME_TTT, GAME_REVERSI = 0, 1
 EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_NET_FP8 = 0, 1, 2, 3, 5
