@@ -29,15 +29,20 @@ def all_gather_example_tensors(tensors, group=None):
 
 
 def gather_examples(engine, group=None):
-    """All ranks get the pooled Examples of every rank's finished games."""
+    """All ranks get the pooled Examples of every rank's finished games (global game ids come from each
+    rank's own game_id_base / game_id_stride, gathered alongside the buffers)."""
     g = all_gather_example_tensors(engine.example_tensors(), group)
     world = dist.get_world_size(group)
+    dev = next(iter(g.values())).device
+    meta = torch.tensor([int(engine.cfg.game_id_base), int(engine.cfg.game_id_stride)], dtype=torch.int64, device=dev)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
     parts = []
-    B = engine.B
+    size = 3 if engine.t_max == 9 else 8
     for r in range(world):
         t = {k: g[k][r].cpu().numpy() for k in _KEYS}
-        parts.append(pack_examples(t, r * B, int(engine.cfg.game_id_stride), 3 if engine.t_max == 9 else 8))
+        base, stride = (int(v) for v in metas[r].cpu())
+        parts.append(pack_examples(t, base, stride, size))
     from .engine import Examples
     cat = lambda f: np.concatenate([getattr(p, f) for p in parts])  # noqa: E731
-    return Examples(cat("own"), cat("opp"), cat("pi"), cat("z"), cat("mover"), cat("act"), cat("game"), cat("ply"),
-                    parts[0].size)
+    return Examples(cat("own"), cat("opp"), cat("pi"), cat("z"), cat("mover"), cat("act"), cat("game"), cat("ply"), size)
