@@ -49,6 +49,19 @@ def _worker(rank, world, port, out):
         ok &= len(ex) == n_rows
         ok &= bool(np.all((ex.game - r * B) % (world * B) < B))  # ids stay in the rank's shard
         total += n_rows
+    # gather_examples() with an engine stand-in: ids come from each rank's own base/stride
+    from types import SimpleNamespace
+    from betazero_amd.distributed import gather_examples
+    fake = SimpleNamespace(example_tensors=lambda: mine, cfg=SimpleNamespace(game_id_base=1000 * rank + 7, game_id_stride=50),
+                           t_max=9, B=B)
+    pooled = gather_examples(fake)
+    ok &= len(pooled) == total
+    ids = set((pooled.game % 1000 if False else pooled.game).tolist())
+    for r in range(world):
+        exp = _fake_buffers(r, R, B, T, na)
+        valid = exp["len"].numpy() > 0
+        want = {1000 * r + 7 + rr * 50 + b for rr in range(R) for b in range(B) if valid[rr, b]}
+        ok &= want <= ids
     out.put((rank, ok, total))
     dist.destroy_process_group()
 
