@@ -43,6 +43,7 @@ _SIGS = {
     "bz_ttt_apply": (i32, [u32, u32, i32, i32, C.POINTER(u32)]),
     "bz_ttt_game_over": (i32, [u32, u32, C.POINTER(i32), C.POINTER(i32)]),
     "bz_reversi_step_batch": (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "bz_reversi_step_batch_sized": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
     "bz_reversi_legal_batch": (i32, [vp, vp, i64, vp, vp]),
     "bz_ttt_step_batch": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
     "bz_augment_d4_batch": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]),

@@ -150,26 +150,26 @@ BZ_EXPORT int32_t bz_ttt_game_over(uint32_t x, uint32_t o, int32_t* over, int32_
 // ---------------------------------------------------------------- kernels
 // one env step; a placement is legal iff the cell is empty and it flips something, so the
 // mover's full legal mask is only needed for the (rare) pass action
-__device__ __forceinline__ void reversi_step_one(u64 me, u64 you, int a, u64& cown, u64& copp, u64& nl, uint8_t& st,
-                                                 int8_t& w) {
+__device__ __forceinline__ void reversi_step_one(u64 me, u64 you, int a, u64 valid, u64& cown, u64& copp, u64& nl,
+                                                 uint8_t& st, int8_t& w) {
     cown = me; copp = you; st = BZ_ST_ILLEGAL; w = 0;
     bool ok;
     if (a == kPass) {
-        nl = rev_legal8(me, you);
+        nl = rev_legal(me, you, valid);
         ok = nl == 0;
         if (ok) { cown = you; copp = me; }
     } else {
-        u64 m = a < 64 ? 1ULL << a : 0ULL;
+        u64 m = a < 64 ? (1ULL << a) & valid : 0ULL;
         u64 f = (m & ~(me | you)) ? rev_flips(me, you, m) : 0ULL;
         ok = f != 0;
         if (ok) { cown = you & ~f; copp = me | m | f; }
-        else nl = rev_legal8(me, you);
+        else nl = rev_legal(me, you, valid);
     }
     if (ok) {
-        nl = rev_legal8(cown, copp);
+        nl = rev_legal(cown, copp, valid);
         st = BZ_ST_RUNNING;
         if (nl == 0) {
-            if (rev_legal8(copp, cown) == 0) {
+            if (rev_legal(copp, cown, valid) == 0) {
                 st = BZ_ST_TERMINAL;
                 int d = popc64(copp) - popc64(cown);  // copp = the player who just moved
                 w = (int8_t)(d > 0 ? 1 : (d < 0 ? -1 : 0));
@@ -182,7 +182,7 @@ __device__ __forceinline__ void reversi_step_one(u64 me, u64 you, int a, u64& co
 
 // 4 games per lane: 2 x 16-byte loads per bitboard array, 4-byte loads/stores of the byte arrays
 __global__ void __launch_bounds__(256) k_reversi_step(const u64* __restrict__ own, const u64* __restrict__ opp,
-                                                      const uint8_t* __restrict__ action, int64_t n,
+                                                      const uint8_t* __restrict__ action, int64_t n, u64 valid,
                                                       u64* __restrict__ own_next, u64* __restrict__ opp_next,
                                                       u64* __restrict__ legal_next, uint8_t* __restrict__ status,
                                                       int8_t* __restrict__ winner) {
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_reversi_step(const u64* __restrict__ ow
         int aa[4] = {ac.x, ac.y, ac.z, ac.w};
         u64 co[4], cp[4], nl[4]; uint8_t st[4]; int8_t w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) reversi_step_one(me[k], you[k], aa[k], co[k], cp[k], nl[k], st[k], w[k]);
+        for (int k = 0; k < 4; ++k) reversi_step_one(me[k], you[k], aa[k], valid, co[k], cp[k], nl[k], st[k], w[k]);
         ulonglong2* on2 = reinterpret_cast<ulonglong2*>(own_next) + 2 * i;
         ulonglong2* pn2 = reinterpret_cast<ulonglong2*>(opp_next) + 2 * i;
         ulonglong2* ln2 = reinterpret_cast<ulonglong2*>(legal_next) + 2 * i;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_reversi_step(const u64* __restrict__ ow
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // ragged tail
         int64_t i = (n4 << 2) + threadIdx.x;
         u64 co, cp, nl; uint8_t st; int8_t w;
-        reversi_step_one(own[i], opp[i], action[i], co, cp, nl, st, w);
+        reversi_step_one(own[i], opp[i], action[i], valid, co, cp, nl, st, w);
         own_next[i] = co; opp_next[i] = cp; legal_next[i] = nl; status[i] = st; winner[i] = w;
     }
 }
@@ -304,20 +304,26 @@ static int grid_for(int64_t n) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));  // <= 256 CUs x 8 blocks, grid-stride the rest
 }
 
-BZ_EXPORT int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
-                                        uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
-                                        uint8_t* status, int8_t* winner, void* stream) {
+BZ_EXPORT int32_t bz_reversi_step_batch_sized(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
+                                              int32_t size, uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
+                                              uint8_t* status, int8_t* winner, void* stream) {
     BZ_REQUIRE(n >= 0 && own && opp && action && own_next && opp_next && legal_next && status && winner,
                "bz_reversi_step_batch: null pointer");
+    BZ_REQUIRE(size_ok(size), "bz_reversi_step_batch: size must be 4, 6 or 8");
     if (n == 0) return BZ_OK;
     BZ_REQUIRE((((uintptr_t)own | (uintptr_t)opp | (uintptr_t)own_next | (uintptr_t)opp_next | (uintptr_t)legal_next) & 15) == 0 &&
                    (((uintptr_t)action | (uintptr_t)status | (uintptr_t)winner) & 3) == 0,
                "bz_reversi_step_batch: arrays must be 16-byte (u64) / 4-byte (u8) aligned");
     ProfScope ps(BZ_PROF_ENV_STEP, stream);
     hipLaunchKernelGGL(k_reversi_step, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, own, opp, action, n,
-                       own_next, opp_next, legal_next, status, winner);
+                       rev_valid(size), own_next, opp_next, legal_next, status, winner);
     BZ_LAUNCH_CHECK("k_reversi_step");
     return BZ_OK;
+}
+BZ_EXPORT int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
+                                        uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
+                                        uint8_t* status, int8_t* winner, void* stream) {
+    return bz_reversi_step_batch_sized(own, opp, action, n, 8, own_next, opp_next, legal_next, status, winner, stream);
 }
 BZ_EXPORT int32_t bz_reversi_legal_batch(const uint64_t* own, const uint64_t* opp, int64_t n, uint64_t* legal,
                                          void* stream) {

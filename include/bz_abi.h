@@ -91,6 +91,11 @@ enum { BZ_ST_RUNNING = 0, BZ_ST_TERMINAL = 1, BZ_ST_ILLEGAL = 2, BZ_ST_MUST_PASS
 int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
                               uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
                               uint8_t* status, int8_t* winner, void* stream);
+/* the same for the reference's smaller boards (size 4, 6 or 8; bit = 8*row+col; actions are bit
+ * indices, 64 = pass) */
+int32_t bz_reversi_step_batch_sized(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
+                                    int32_t size, uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
+                                    uint8_t* status, int8_t* winner, void* stream);
 int32_t bz_reversi_legal_batch(const uint64_t* own, const uint64_t* opp, int64_t n, uint64_t* legal,
                                void* stream);
 /* Tic-tac-toe: to_move[n] = absolute colour (+1/-1) of the mover; winner is the

@@ -562,3 +562,29 @@ def test_selfplay_longer_searches_vs_oracle_bitexact():
     _check_selfplay("reversi", 64, 100, "hash", 8, 1, 21, base=1000)
     _check_selfplay("ttt", 256, 200, "hash", 9, 0, 4)      # 200 sims: the tree saturates into terminals
     _check_selfplay("ttt", 64, 60, "uniform", 3, 0, 2, base=7)
+
+
+@pytest.mark.parametrize("size", [4, 6])
+def test_reversi_step_batch_small_boards_on_golden_games(size):
+    """the reference's 4x4 / 6x6 boards (reversi_board.py:93, reversi_terminal.py:46) through the batched kernel"""
+    d = np.load(os.path.join(G, "reversi_random_games.npz"))
+    rows = d["rows"][d["rows"][:, 1] == size]
+    cur = rows[:, 3].astype(np.int64) - 1
+    own = np.where(cur == 1, rows[:, 4], rows[:, 5])
+    opp = np.where(cur == 1, rows[:, 5], rows[:, 4])
+    act = np.where(rows[:, 7] == 255, 64, rows[:, 7]).astype(np.uint8)
+    n = len(rows)
+    o, p, a = _dev_u64(own), _dev_u64(opp), torch.as_tensor(act).to(DEV)
+    on, pn, lg = (torch.empty(n, dtype=torch.int64, device=DEV) for _ in range(3))
+    st = torch.empty(n, dtype=torch.uint8, device=DEV)
+    w = torch.empty(n, dtype=torch.int8, device=DEV)
+    _lib.check(_lib.lib().bz_reversi_step_batch_sized(o.data_ptr(), p.data_ptr(), a.data_ptr(), n, size, on.data_ptr(),
+                                                      pn.data_ptr(), lg.data_ptr(), st.data_ptr(), w.data_ptr(), _stream()))
+    on, pn, lg, st = on.cpu().numpy().view(np.uint64), pn.cpu().numpy().view(np.uint64), lg.cpu().numpy().view(np.uint64), st.cpu().numpy()
+    for i in range(n):
+        exp = (int(own[i]), int(opp[i]), 0) if act[i] == 64 else orc.reversi_apply(int(own[i]), int(opp[i]), size, int(act[i]) >> 3, int(act[i]) & 7)
+        assert (int(pn[i]), int(on[i])) == (exp[0], exp[1])
+        assert int(lg[i]) == orc.reversi_legal(exp[1], exp[0], size)
+        assert (st[i] == _lib.ST_TERMINAL) == bool(rows[i, 9])
+    same = rows[1:, 0] == rows[:-1, 0]
+    assert np.array_equal(lg[:-1][same], rows[1:, 6][same])  # next row's legal mask in the fixture
