@@ -236,7 +236,7 @@ def main():
             out["dtype"] = args.precision
             out["config"] = {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{args.precision}",
                              "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8,
-                             "openings": 12, "net": "stem + 6 residual blocks x 128 ch, random init seed 0",
+                             "openings": 12, "evaluator": "policy/value conv tower 6x128 (226.86 MFLOP per leaf), random init seed 0",
                              "step": "one move for all concurrent games (steady-state pool, staggered starts)"
                              if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",
                              "pipelines": f"{NS} x {Bs} games on separate HIP streams",
