@@ -36,3 +36,28 @@ def test_examples_csv_roundtrip(tmp_path):
     assert np.array_equal(back["State"], ex.states().reshape(n, 9))
     assert np.array_equal(back["Pi"], pi) and np.array_equal(back["Z"], ex.z)
     assert np.array_equal(back["Action"].argmax(1), ex.act)
+
+
+def test_e4m3_quantiser_matches_the_oracle_and_is_idempotent():
+    """betazero_amd.quant.e4m3_round (numpy) == the oracle's C rounding on a dense sweep; per-channel
+    scales are powers of two that put max|w| in (224, 448]; fake-quantisation is idempotent."""
+    import torch
+    from betazero_amd.net import PolicyValueNet
+    from betazero_amd.quant import channel_scale, e4m3_round, fake_quantize_fp8_
+    from oracle import oracle as orc
+    r0, r1 = np.random.default_rng(0), np.random.default_rng(1)
+    xs = np.concatenate([np.linspace(0, 500, 5001), 2.0 ** np.arange(-14, 9).astype(np.float64),
+                         r0.random(5000) * 2.0 ** r1.integers(-12, 9, 5000).astype(np.float64)]).astype(np.float32)
+    xs = np.concatenate([xs, -xs])
+    a = e4m3_round(xs)
+    b = np.array([orc.lib().orc_e4m3_round(float(x)) for x in xs], dtype=np.float32)
+    assert np.array_equal(a, b) and len(np.unique(np.abs(a))) == 127 and np.abs(a).max() == 448
+    w = r0.normal(0, 0.03, (16, 9 * 128)).astype(np.float32)
+    s = channel_scale(w)
+    m = np.abs(w).max(1) * s
+    assert np.all(np.log2(s) == np.round(np.log2(s))) and np.all(m > 224) and np.all(m <= 448)
+    torch.manual_seed(1)
+    net = fake_quantize_fp8_(PolicyValueNet(32, 1, 64))
+    p1 = net.flat_params().copy()
+    p2 = fake_quantize_fp8_(net).flat_params()
+    assert np.array_equal(p1, p2)
