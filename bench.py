@@ -86,12 +86,60 @@ def cpu_baseline_ttt(sims):
             "sample": f"{cores} threads x {per} complete TTT games ({sims} sims/move, uniform priors) in {dt:.1f} s"}
 
 
+def bench_net_only(args, rank, world, dev):
+    import numpy as np
+    import torch
+    from betazero_amd import _lib
+    from betazero_amd.net import DeviceNet, PolicyValueNet
+    from betazero_amd.quant import fake_quantize_fp8_
+    B = args.games or 8192
+    K = args.steps if args.steps is not None else 1000
+    W = args.warmup if args.warmup is not None else 50
+    fp8 = args.precision != "bf16" or "--precision" not in sys.argv  # cfg 5 is the fp8 run unless bf16 is asked for
+    torch.manual_seed(0)
+    mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
+    if fp8:
+        fake_quantize_fp8_(mod)
+    net = DeviceNet.from_module(mod, B, dev)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "reversi_random_games.npz"))["rows"]
+    d = d[d[:, 1] == 8]
+    idx = np.arange(B) % len(d)  # positions sampled from fixture F1, tiled to the batch
+    own = torch.as_tensor(d[idx, 4].copy().view(np.int64)).to(dev)
+    opp = torch.as_tensor(d[idx, 5].copy().view(np.int64)).to(dev)
+    L = _lib.lib()
+    for _ in range(W):
+        net.forward(own, opp, fp8=fp8)
+    L.bz_profile_reset(); L.bz_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        net.forward(own, opp, fp8=fp8)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.bz_profile_enable(0)
+    launches, timed, ms = _lib.profile_read()["tower"]
+    avg_ms = ms / max(timed, 1)
+    peak = 2 * MFMA_PEAK_TFLOPS if fp8 else MFMA_PEAK_TFLOPS
+    ach = B * NET_FLOP_PER_POS / (avg_ms * 1e-3) / 1e12
+    if rank == 0:
+        print(json.dumps({"metric": "net_leaf_evals_per_s", "value": B * K * world / dt, "unit": "evals/s", "n_gpus": world,
+                          "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if fp8 else "bf16", "data": "synthetic",
+                          "config": {"workload": f"reversi8x8_net_forward_batch{B}_{'fp8' if fp8 else 'bf16'}",
+                                     "positions": "fixture F1 positions tiled to the batch"},
+                          "roofline": {"bound": "mfma", "kernel": "f8::k_tower_fp8" if fp8 else "k_tower_bf16",
+                                       "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                       "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
+                                       "flop_per_launch": B * NET_FLOP_PER_POS}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt"])
+    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt", "net"],
+                    help="reversi = BASELINE cfg 3 (default, the metric), ttt = cfg 2, net = cfg 5 (net forward only)")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +177,8 @@ def main():
     _lib.require_gpu()
     L = _lib.lib()
 
+    if args.workload == "net":  # BASELINE cfg 5: leaf-eval batch 8192, fp8 e4m3 net, MFMA-utilisation run
+        return bench_net_only(args, rank, world, dev)
     reversi = args.workload == "reversi"
     B = args.games or (4096 if reversi else 65536)
     sims = args.sims or (800 if reversi else 50)
