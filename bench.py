@@ -325,7 +325,7 @@ def main():
             tb = tree_bytes(cnt)
             tree_ms = prof["select"][2] * prof["select"][0] / max(prof["select"][1], 1) + \
                 prof["expand_backup"][2] * prof["expand_backup"][0] / max(prof["expand_backup"][1], 1)
-            out["roofline_tree"] = {"bound": "hbm", "kernels": "k_select + k_expand_backup",
+            out["roofline_tree"] = {"bound": "hbm", "kernels": "k_tree_step (expand + backup + select, 16 lanes per game)",
                                     "achieved": tb / (tree_ms * 1e-3) / 1e9 if tree_ms else None,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": tb / (tree_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tree_ms else None,
