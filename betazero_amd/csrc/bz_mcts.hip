@@ -271,7 +271,7 @@ __device__ __forceinline__ void dev_start_game(const EngineDev& E, int g, int ro
     u64 own, opp;
     G::start(&own, &opp);
     int tm = 1, made = 0;
-    if (G::kGame == 1 && E.openings) {
+    if (G::kGame == 1 && E.openings) {  // the 12 two-ply openings are an 8x8 notion
         u64 gid = E.id_base + (u64)round * E.id_stride + (u64)g;
         int k = (int)(gid % 12ULL);
         int pick[2] = {k / 3, k % 3};
@@ -559,7 +559,7 @@ struct Offsets {
 };
 
 bool cfg_ok(const bz_engine_cfg* c) {
-    return c && (c->game == BZ_GAME_TTT || c->game == BZ_GAME_REVERSI) && c->n_games > 0 && c->sims >= 1 &&
+    return c && c->game >= BZ_GAME_TTT && c->game <= BZ_GAME_REVERSI4 && c->n_games > 0 && c->sims >= 1 &&
            c->sims < (1 << 20) && c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_NET_FP8 && c->rounds >= 1 &&
            c->t_max >= 1;
 }
@@ -599,27 +599,22 @@ inline dim3 grid_of(int B) { return dim3((B + 255) / 256); }
 inline dim3 grid_groups(int B, int gw) { return dim3(((size_t)B * gw + 255) / 256); }
 }  // namespace
 
-#define BZ_DISPATCH_G(e, KERNEL, stream, ...)                                                           \
-    do {                                                                                                \
-        if ((e)->cfg.game == BZ_GAME_TTT)                                                               \
-            hipLaunchKernelGGL(KERNEL<TicTacToe>, grid_groups((e)->dev.B, TicTacToe::GW), dim3(256), 0, (hipStream_t)(stream), \
-                               __VA_ARGS__);                                                            \
-        else                                                                                            \
-            hipLaunchKernelGGL(KERNEL<Reversi>, grid_groups((e)->dev.B, Reversi::GW), dim3(256), 0, (hipStream_t)(stream),   \
-                               __VA_ARGS__);                                                            \
-        BZ_LAUNCH_CHECK(#KERNEL);                                                                       \
+#define BZ_LAUNCH_ONE(G, KERNEL, grid, stream, ...) \
+    hipLaunchKernelGGL(KERNEL<G>, grid, dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__)
+#define BZ_DISPATCH_IMPL(e, KERNEL, GRIDFN, stream, ...)                                                        \
+    do {                                                                                                        \
+        switch ((e)->cfg.game) {                                                                                \
+        case BZ_GAME_TTT: BZ_LAUNCH_ONE(TicTacToe, KERNEL, GRIDFN((e)->dev.B, TicTacToe::GW), stream, __VA_ARGS__); break; \
+        case BZ_GAME_REVERSI6: BZ_LAUNCH_ONE(Reversi6, KERNEL, GRIDFN((e)->dev.B, Reversi6::GW), stream, __VA_ARGS__); break; \
+        case BZ_GAME_REVERSI4: BZ_LAUNCH_ONE(Reversi4, KERNEL, GRIDFN((e)->dev.B, Reversi4::GW), stream, __VA_ARGS__); break; \
+        default: BZ_LAUNCH_ONE(Reversi, KERNEL, GRIDFN((e)->dev.B, Reversi::GW), stream, __VA_ARGS__); break;      \
+        }                                                                                                       \
+        BZ_LAUNCH_CHECK(#KERNEL);                                                                               \
     } while (0)
-
-#define BZ_DISPATCH(e, KERNEL, stream, ...)                                                             \
-    do {                                                                                                \
-        if ((e)->cfg.game == BZ_GAME_TTT)                                                               \
-            hipLaunchKernelGGL(KERNEL<TicTacToe>, grid_of((e)->dev.B), dim3(256), 0, (hipStream_t)(stream), \
-                               __VA_ARGS__);                                                            \
-        else                                                                                            \
-            hipLaunchKernelGGL(KERNEL<Reversi>, grid_of((e)->dev.B), dim3(256), 0, (hipStream_t)(stream),   \
-                               __VA_ARGS__);                                                            \
-        BZ_LAUNCH_CHECK(#KERNEL);                                                                       \
-    } while (0)
+inline dim3 grid_lane(int B, int) { return grid_of(B); }
+// one lane per game / G::GW lanes per game
+#define BZ_DISPATCH(e, KERNEL, stream, ...) BZ_DISPATCH_IMPL(e, KERNEL, grid_lane, stream, __VA_ARGS__)
+#define BZ_DISPATCH_G(e, KERNEL, stream, ...) BZ_DISPATCH_IMPL(e, KERNEL, grid_groups, stream, __VA_ARGS__)
 
 BZ_EXPORT int64_t bz_engine_workspace_bytes(const bz_engine_cfg* cfg) {
     if (!cfg_ok(cfg)) { set_error("bz_engine_workspace_bytes: bad config"); return -1; }

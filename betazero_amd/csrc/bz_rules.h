@@ -95,10 +95,14 @@ BZ_HD bool ttt_over(u32 x, u32 o, int* winner) {
 }
 
 // ---- game traits used by the tree / self-play kernels (8x8 Reversi, 3x3 TTT)
-struct Reversi {
-    static constexpr int kGame = 1, NA = 65, MAXCH = 34, MAXD = 128;
+// SIZE = 8 is the benchmark game; 6 and 4 are the reference's demo boards (reversi_gui.py:105,
+// reversi_terminal.py:46, reversi_board.py:93).  All sizes share bit = 8*row+col and NA = 65.
+template <int SIZE>
+struct ReversiT {
+    static constexpr int kGame = SIZE == 8 ? 1 : (SIZE == 6 ? 2 : 3), NA = 65, MAXCH = 34, MAXD = 128;
     static constexpr int GW = 16;  // lanes that serve one game in the tree kernels (mean branching 8.5, max 33)
-    static BZ_HD u64 legal(u64 own, u64 opp) { return rev_legal8(own, opp); }
+    static constexpr u64 kValid = SIZE == 8 ? ~0ULL : (SIZE == 6 ? 0x00003F3F3F3F3F3FULL : 0x000000000F0F0F0FULL);
+    static BZ_HD u64 legal(u64 own, u64 opp) { return rev_legal(own, opp, kValid); }
     // position after action a, seen by the next mover
     static BZ_HD void apply(u64 own, u64 opp, int a, u64* cown, u64* copp) {
         if (a == kPass) { *cown = opp; *copp = own; return; }
@@ -109,16 +113,20 @@ struct Reversi {
     // terminal test for a node whose mover has absolute colour to_move;
     // *tv = outcome for that mover
     static BZ_HD bool terminal(u64 own, u64 opp, int to_move, u64 legal_own, int* tv) {
-        if (legal_own != 0 || rev_legal8(opp, own) != 0) return false;
+        if (legal_own != 0 || rev_legal(opp, own, kValid) != 0) return false;
         int d = popc64(own) - popc64(opp);  // get_score, reversi_board.py:68-76
         *tv = d > 0 ? 1 : (d < 0 ? -1 : 0);
         return true;
     }
     static BZ_HD void start(u64* own, u64* opp) {  // reversi_board.py:9-11, +1 moves first
-        *own = (1ULL << 27) | (1ULL << 36);
-        *opp = (1ULL << 28) | (1ULL << 35);
+        constexpr int p = SIZE / 2 - 1;
+        *own = (1ULL << (8 * p + p)) | (1ULL << (8 * (p + 1) + p + 1));
+        *opp = (1ULL << (8 * p + p + 1)) | (1ULL << (8 * (p + 1) + p));
     }
 };
+typedef ReversiT<8> Reversi;
+typedef ReversiT<6> Reversi6;
+typedef ReversiT<4> Reversi4;
 struct TicTacToe {
     static constexpr int kGame = 0, NA = 9, MAXCH = 9, MAXD = 16;
     static constexpr int GW = 4;   // 16 games per wave

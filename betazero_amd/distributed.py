@@ -38,7 +38,7 @@ def gather_examples(engine, group=None):
     metas = [torch.empty_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
     parts = []
-    size = 3 if engine.t_max == 9 else 8
+    size = getattr(engine, "size", 3 if engine.t_max == 9 else 8)
     for r in range(world):
         t = {k: g[k][r].cpu().numpy() for k in _KEYS}
         base, stride = (int(v) for v in metas[r].cpu())

@@ -8,11 +8,13 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (EVAL_EXTERNAL, EVAL_HASH, EVAL_NET_BF16, EVAL_NET_F32, EVAL_NET_FP8, EVAL_UNIFORM, GAME_REVERSI, GAME_TTT,
-                   EngineCfg, EngineLayout)
+from ._lib import (EVAL_EXTERNAL, EVAL_HASH, EVAL_NET_BF16, EVAL_NET_F32, EVAL_NET_FP8, EVAL_UNIFORM, GAME_REVERSI,
+                   GAME_REVERSI4, GAME_REVERSI6, GAME_TTT, EngineCfg, EngineLayout)
 
-_GAMES = {"ttt": GAME_TTT, "tic_tac_toe": GAME_TTT, "reversi": GAME_REVERSI, GAME_TTT: GAME_TTT,
-          GAME_REVERSI: GAME_REVERSI}
+_GAMES = {"ttt": GAME_TTT, "tic_tac_toe": GAME_TTT, "reversi": GAME_REVERSI, "reversi8": GAME_REVERSI,
+          "reversi6": GAME_REVERSI6, "reversi4": GAME_REVERSI4, GAME_TTT: GAME_TTT, GAME_REVERSI: GAME_REVERSI,
+          GAME_REVERSI6: GAME_REVERSI6, GAME_REVERSI4: GAME_REVERSI4}
+_SIZES = {GAME_TTT: 3, GAME_REVERSI: 8, GAME_REVERSI6: 6, GAME_REVERSI4: 4}
 _EVALS = {"uniform": EVAL_UNIFORM, "hash": EVAL_HASH, "net_f32": EVAL_NET_F32, "net_bf16": EVAL_NET_BF16,
           "external": EVAL_EXTERNAL, "net_fp8": EVAL_NET_FP8}
 
@@ -71,6 +73,7 @@ class SelfPlayEngine:
         self.lay = EngineLayout()
         _lib.check(L.bz_engine_get_layout(self.h, C.byref(self.lay)))
         self.B, self.sims, self.rounds, self.na, self.t_max = n_games, sims, rounds, self.lay.na, t_max
+        self.size = _SIZES[self.game]
         self.net = net
         if net is not None:
             _lib.check(L.bz_engine_set_net(self.h, net.h))
@@ -172,7 +175,7 @@ class SelfPlayEngine:
     def examples(self):
         return pack_examples({k: v.cpu().numpy() for k, v in self.example_tensors().items()},
                              int(self.cfg.game_id_base), int(self.cfg.game_id_stride),
-                             3 if self.game == GAME_TTT else 8)
+                             _SIZES[self.game])
 
     def winners(self):
         t = self.example_tensors()

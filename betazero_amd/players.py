@@ -86,9 +86,9 @@ class MCTSPlayer(Player):
         return self._eng[game]
 
     def get_move(self, board):
-        game = "reversi" if hasattr(board, "size") else "ttt"
-        if game == "reversi" and board.size != 8:
-            raise ValueError("MCTSPlayer supports 8x8 Reversi boards")
+        game = {8: "reversi", 6: "reversi6", 4: "reversi4"}[board.size] if hasattr(board, "size") else "ttt"
+        if game != "reversi" and self.evaluator.startswith("net"):
+            raise ValueError("the conv net evaluators serve 8x8 Reversi only; use evaluator='uniform' or 'hash'")
         own, opp = board.bits(self.symbol)
         eng = self._engine(game)
         eng.set_roots([own], [opp], [self.symbol])

@@ -298,6 +298,9 @@ class Twin:
     """Sequential MCTS over the reference's board objects (spec M1-M5)."""
 
     def __init__(self, game, eval_kind, c_puct=1.5):
+        self.size = {"reversi6": 6, "reversi4": 4}.get(game, 8)
+        self.label = game
+        game = "reversi" if game.startswith("reversi") else game
         self.game, self.eval_kind, self.c = game, eval_kind, f32(c_puct)
         self.na = 9 if game == "ttt" else 65
 
@@ -393,9 +396,9 @@ class Twin:
         if self.game == "ttt":
             b = TicTacToeBoard()
         else:
-            b = ReversiBoard()
+            b = ReversiBoard(size=self.size)
         p, made, passes = 1, 0, 0
-        if self.game == "reversi" and openings:
+        if self.game == "reversi" and openings and self.size == 8:
             k = gid % 12
             for pick in (k // 3, k % 3):
                 a = self.moves(b, p)[pick]
@@ -491,6 +494,20 @@ def gen_f7():
     add_selfplay("reversi", "hash", 0, 12, 0, 0, 0)
     add_selfplay("reversi", "hash", 7, 10, 8, 1, 0)     # cfg 3 diversification rules
     add_selfplay("reversi", "uniform", 10, 8, 8, 1, 3)
+    # the reference's demo board sizes (appended: earlier case ids stay stable)
+    add_search("reversi6", "hash", ReversiBoard(size=6), 1, 120, "6x6 start")
+    add_search("reversi4", "hash", ReversiBoard(size=4), 1, 200, "4x4 start: the tree runs into terminals")
+    b6, p6 = ReversiBoard(size=6), 1
+    for k in range(14):
+        mv = b6.generate_possible_moves(p6)
+        if mv:
+            b6 = b6.make_move(*rnd.choice(mv), p6)
+        p6 = -p6
+    if b6.generate_possible_moves(p6) and not b6.is_game_over():
+        add_search("reversi6", "uniform", b6, p6, 90, "6x6 random ply 14")
+    add_selfplay("reversi6", "hash", 2, 14, 6, 0, 5)
+    add_selfplay("reversi4", "hash", 1, 20, 2, 0, 0)
+    add_selfplay("reversi4", "uniform", 3, 30, 0, 0, 0)
     np.savez_compressed(os.path.join(OUT, "mcts_twin.npz"), **out)
     with open(os.path.join(OUT, "mcts_twin.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("BZ_ORACLE_SO", os.path.join(_HERE, "libbz_oracle.so"))  # BZ_ORACLE_SO: e.g. the ASan build
 
-GAME_TTT, GAME_REVERSI = 0, 1
+GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3
 EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_NET_FP8 = 0, 1, 2, 3, 5
 PASS = 64
 COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",

@@ -168,7 +168,8 @@ def test_search_matches_golden_twin_and_oracle(fused):
             assert np.array_equal(N[g], d[f"s{i}_N"]), case
             assert np.array_equal(W[g].view(np.uint32), d[f"s{i}_W"].view(np.uint32)), case
             assert np.array_equal(P[g].view(np.uint32), d[f"s{i}_P"].view(np.uint32)), case
-        _, _, _, cnt = orc.mcts_search(orc.GAME_TTT if case["game"] == "ttt" else orc.GAME_REVERSI, case["own"],
+        _, _, _, cnt = orc.mcts_search({"ttt": orc.GAME_TTT, "reversi": orc.GAME_REVERSI, "reversi6": orc.GAME_REVERSI6,
+                                        "reversi4": orc.GAME_REVERSI4}[case["game"]], case["own"],
                                        case["opp"], case["to_move"], case["sims"],
                                        orc.EVAL_UNIFORM if ev == "uniform" else orc.EVAL_HASH)
         got = eng.counters()
@@ -588,3 +589,57 @@ def test_reversi_step_batch_small_boards_on_golden_games(size):
         assert (st[i] == _lib.ST_TERMINAL) == bool(rows[i, 9])
     same = rows[1:, 0] == rows[:-1, 0]
     assert np.array_equal(lg[:-1][same], rows[1:, 6][same])  # next row's legal mask in the fixture
+
+
+def test_small_reversi_boards_search_and_selfplay_vs_twin_and_oracle():
+    """6x6 / 4x4 Reversi (the reference's demo sizes) through the same tree kernels: root statistics and
+    whole self-play games vs the Python twin over the reference's boards (fixture) and vs the oracle"""
+    d = np.load(os.path.join(G, "mcts_twin.npz"))
+    games = {"reversi6": orc.GAME_REVERSI6, "reversi4": orc.GAME_REVERSI4}
+    n_checked = 0
+    for case in _cases("search"):
+        if case["game"] not in games:
+            continue
+        eng = _engine(case["game"], 2, case["sims"], case["eval"])
+        eng.set_roots([case["own"]] * 2, [case["opp"]] * 2, [case["to_move"]] * 2)
+        eng.search()
+        N, W, P = eng.root_stats()
+        eng.status()
+        i = case["id"]
+        assert np.array_equal(N[1], d[f"s{i}_N"]) and np.array_equal(W[1].view(np.uint32), d[f"s{i}_W"].view(np.uint32))
+        assert np.array_equal(P[0].view(np.uint32), d[f"s{i}_P"].view(np.uint32))
+        n_checked += 1
+    for case in _cases("selfplay"):
+        if case["game"] not in games:
+            continue
+        eng = _engine(case["game"], 1, case["sims"], case["eval"], temp_moves=case["temp_moves"], seed=case["seed"],
+                      game_id_base=case["gid"])
+        eng.run_iteration()
+        ex = eng.examples()
+        i = case["id"]
+        assert np.array_equal(ex.own, d[f"g{i}_own"]) and np.array_equal(ex.act, d[f"g{i}_act"])
+        assert np.array_equal(ex.pi.view(np.uint32), d[f"g{i}_pi"].view(np.uint32))
+        assert eng.winners()[0][0, 0] == case["winner"]
+        n_checked += 1
+    assert n_checked == 6
+    for name, og in games.items():  # a batch of games vs the oracle
+        eng = _engine(name, 40, 30, "hash", temp_moves=4, seed=3, game_id_base=50)
+        eng.run_iteration()
+        ex = eng.examples()
+        winners, lens = eng.winners()
+        for g in range(40):
+            r = orc.selfplay_game(og, 50 + g, 30, orc.EVAL_HASH, 4, 0, 3)
+            m = ex.game == 50 + g
+            assert lens[0, g] == len(r["own"]) and winners[0, g] == r["winner"]
+            assert np.array_equal(ex.act[m], r["act"]) and np.array_equal(ex.pi[m].view(np.uint32), r["pi"].view(np.uint32))
+        assert ex.states().shape[1:] == ({"reversi6": 6, "reversi4": 4}[name],) * 2
+
+
+def test_mcts_player_on_the_reference_demo_board_sizes():
+    import random
+    import betazero_amd as bz
+    random.seed(2)
+    for size in (4, 6):  # reversi_terminal.py:42-47 plays on 4x4, reversi_gui.py:105 on 6x6
+        g = bz.ReversiHeadless(bz.MCTSPlayer(1, sims=60, evaluator="hash"), bz.ReversiRandomPlayer(-1), size=size)
+        positions, winner = g.play()
+        assert g.board.is_game_over() and winner in (-1, 0, 1)
