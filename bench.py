@@ -4,7 +4,10 @@
 Default workload = BASELINE config 3: Reversi 8x8, 4096 concurrent games per GPU,
 800 MCTS simulations per move, random-init 6x128 conv policy/value net in bf16
 (MFMA), tau=1 for moves < 8 + 12 fixed two-ply openings.  `--workload ttt` runs
-BASELINE config 2 (65,536 TTT games, 50 sims, uniform priors, tree kernels only).
+BASELINE config 2 (65,536 TTT games, 50 sims, uniform priors, tree kernels only),
+`--workload net` config 5 (net forward only, batch 8192, fp8).  The default run also
+measures configs 2 and 5 briefly after the headline measurement and attaches them
+as `secondary` (driver-timed evidence for their rooflines; not part of `value`).
 
 A "step" (reversi) = one move for every concurrent game: root expansion + 800 x
 (select -> net -> expand/backup) + move choice / example row / env step.  The
@@ -17,11 +20,16 @@ A "step" (ttt) = one complete iteration: all 65,536 games played to the end.
 
 N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL), games sharded
 by global id (weak scaling: 4096 per GPU), no data-path collective except ONE
-all-gather of the (s, pi, z) buffers at the end of the timed region.
+all-gather of the example blocks at the end of the timed region.
+`python bench.py --gpus N` starts the N ranks itself (torch.distributed.run
+children, before this process touches a GPU); under an external torchrun
+(WORLD_SIZE set) it is a rank and `--gpus` must equal the world size.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -31,9 +39,10 @@ sys.path.insert(0, ROOT)
 
 TOWER_FLOP_PER_POS = 12 * 2 * 64 * 9 * 128 * 128      # 226.49e6: the 12 conv3x3 layers of k_tower_bf16
 NET_FLOP_PER_POS = 226.86e6                           # stem + tower + heads
-MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md (fp8: 2x)
 HBM_PEAK_GBS = 8000.0
 PLIES_PER_GAME = 58                                   # searched moves per cfg-3 game (60 - 2 opening plies)
+PMC_TRAFFIC = ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json")
 
 
 def tree_bytes(c):
@@ -42,17 +51,88 @@ def tree_bytes(c):
             13 * c["n_child_written"] + 264 * c["n_net_leaves"] + 42 * c["n_env_steps"])
 
 
-def cpu_baseline_reversi(sims, seconds_hint=20):
-    """oracle (CPU restatement, kind "port") on the host cores: `cores` threads x 2 searched
-    moves of cfg-3 games each (bf16-emulating net), extrapolated at 58 searched moves/game"""
+def host_cores():
+    return max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+
+
+# ------------------------------------------------------------------ N ranks from one command
+def launch_ranks(n, argv):
+    """parent of `python bench.py --gpus N`: start N fresh rank processes and relay their status.
+    Nothing here touches a GPU (not even `import torch`), and nothing is exec'ed from a process
+    that has: the ranks are children."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def rehearsal(args, rank, world):
+    """CPU-only rehearsal of the N>1 plumbing (no GPU in this process, BZ_BENCH_REHEARSAL=1):
+    process group, barrier + max-over-ranks timing and the single all-gather on example blocks of
+    the engine's exact layout.  Measures nothing about the hot path and says so."""
+    import torch
+    import torch.distributed as dist
+    from betazero_amd import distributed as bd
+    from betazero_amd.engine import build_example_block, unpack_example_block
+    B, NS, R, T, na = args.games or 256, max(1, args.streams), 2, 64, 65
+    Bs = B // NS
+    g = torch.Generator().manual_seed(rank)
+    blocks = []
+    for i in range(NS):
+        ln = torch.randint(40, T - 4, (R, Bs), generator=g, dtype=torch.int32)
+        ln[1] = -1  # second round unfinished
+        arr = {"own": torch.randint(0, 2**62, (R, Bs, T), generator=g, dtype=torch.int64),
+               "opp": torch.zeros((R, Bs, T), dtype=torch.int64), "pi": torch.rand((R, Bs, T, na), generator=g),
+               "z": torch.zeros((R, Bs, T), dtype=torch.int8), "mover": torch.ones((R, Bs, T), dtype=torch.int8),
+               "act": torch.zeros((R, Bs, T), dtype=torch.uint8), "len": ln, "winner": torch.zeros((R, Bs), dtype=torch.int8)}
+        blocks.append(build_example_block(arr, rank * B + i * Bs, world * B, "reversi"))
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    K = args.steps if args.steps is not None else 2
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        time.sleep(0.01)  # stands in for a step
+    gathered, sizes = bd.all_gather_example_blocks(blocks)
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    rows = sum(len(unpack_example_block(b)) for row in bd.split_gathered(gathered, sizes) for b in row)
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "selfplay_games_per_s", "value": None, "unit": "games/s", "n_gpus": dist.get_world_size(),
+                          "steps": K, "warmup": args.warmup or 0, "ms_per_step": float(t[0]) / K * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "synthetic", "rehearsal": True,
+                          "config": {"workload": "CPU rehearsal of the multi-rank plumbing only (no GPU in this "
+                                                 "process): launcher, process group, one all-gather, timing"},
+                          "collectives": len(calls), "block_bytes_per_rank": int(sum(sizes)),
+                          "gathered_bytes": int(gathered.numel()), "pooled_rows": int(rows)}))
+
+
+# ------------------------------------------------------------------ CPU baselines (rank 0, N = 1)
+def cpu_baseline_reversi(sims, budget_s=12.0):
+    """(i) "port": the C oracle on ALL host cores, one game per thread, 2 searched moves each of cfg-3
+    games with the bf16-emulating net, extrapolated at 58 searched moves per game.
+    (ii) "python_loop": the build-authored Python MCTS twin (oracle/py_twin.py) over betazero_amd's
+    API-compatible ReversiBoard with a batch-1 torch CPU forward of the same net per leaf (the calling
+    convention of the reference's AIPlayer, players.py:84-98), ONE core, a time-bounded share of one
+    800-simulation search, extrapolated.  The reference has no MCTS loop to time."""
     import numpy as np
     import torch
-    from betazero_amd.net import PolicyValueNet
+    from betazero_amd.net import PolicyValueNet, bits_to_planes
     from oracle import oracle as orc
     torch.manual_seed(0)
     mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
     net = orc.Net(128, 6, 64, mod.flat_params())
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    cores = host_cores()
     moves = 2
     done = [0] * cores
 
@@ -64,14 +144,46 @@ def cpu_baseline_reversi(sims, seconds_hint=20):
     [t.start() for t in th]
     [t.join() for t in th]
     dt = time.time() - t0
-    return {"value": sum(done) / dt / PLIES_PER_GAME, "unit": "games/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} threads x {moves} searched moves ({sims} sims, {sims + 1} net evals per move) of "
-                      f"cfg-3 games in {dt:.1f} s; extrapolated at {PLIES_PER_GAME} searched moves per game"}
+    out = {"value": sum(done) / dt / PLIES_PER_GAME, "unit": "games/s", "cores": cores, "kind": "port",
+           "sample": f"{cores} threads x {moves} searched moves ({sims} sims, {sims + 1} net evals per move) of "
+                     f"cfg-3 games in {dt:.1f} s; extrapolated at {PLIES_PER_GAME} searched moves per game"}
+    # (ii) the Python loop, one core
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import py_twin
+        import betazero_amd as bz
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+        class NetTwin(py_twin.Twin):
+            def evaluate(self, b, p):
+                own, opp = self.bits(b, p)
+                with torch.no_grad():
+                    lg, v = mod(bits_to_planes(np.array([own], np.uint64), np.array([opp], np.uint64)))
+                return [np.float32(x) for x in lg[0].tolist()], np.float32(float(v[0]))
+        tw = NetTwin("reversi", "net", boards=(bz.ReversiBoard, bz.TicTacToeBoard))
+        t0 = time.time()
+        root = tw.new_node(bz.ReversiBoard(), 1)
+        tw.expand(root)
+        n = 0
+        while n < sims and time.time() - t0 < budget_s:
+            tw.simulate(root)
+            n += 1
+        dtp = time.time() - t0
+        torch.set_num_threads(nthr)
+        per_move = dtp / max(n, 1) * sims
+        out["python_loop"] = {"value": 1.0 / (per_move * PLIES_PER_GAME), "unit": "games/s", "cores": 1,
+                              "kind": "build-authored Python MCTS over betazero_amd.ReversiBoard + batch-1 torch CPU net",
+                              "sample": f"{n} of the {sims} simulations of one search from the start position in "
+                                        f"{dtp:.1f} s; extrapolated to {sims} sims x {PLIES_PER_GAME} searched moves"}
+    except Exception as e:  # the baseline must never take the bench line down
+        out["python_loop"] = {"value": None, "error": repr(e)}
+    return out
 
 
 def cpu_baseline_ttt(sims):
     from oracle import oracle as orc
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+    cores = host_cores()
     per = 4000
     t0 = time.time()
 
@@ -86,51 +198,253 @@ def cpu_baseline_ttt(sims):
             "sample": f"{cores} threads x {per} complete TTT games ({sims} sims/move, uniform priors) in {dt:.1f} s"}
 
 
-def bench_net_only(args, rank, world, dev):
+# ------------------------------------------------------------------ the three workloads
+class Ctx:
+    pass
+
+
+def run_net(ctx, B, K, W, fp8):
+    """BASELINE cfg 5: net forward only on a batch of fixture-F1 positions"""
     import numpy as np
     import torch
     from betazero_amd import _lib
     from betazero_amd.net import DeviceNet, PolicyValueNet
     from betazero_amd.quant import fake_quantize_fp8_
-    B = args.games or 8192
-    K = args.steps if args.steps is not None else 1000
-    W = args.warmup if args.warmup is not None else 50
-    fp8 = args.precision != "bf16" or "--precision" not in sys.argv  # cfg 5 is the fp8 run unless bf16 is asked for
     torch.manual_seed(0)
     mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
     if fp8:
         fake_quantize_fp8_(mod)
-    net = DeviceNet.from_module(mod, B, dev)
+    net = DeviceNet.from_module(mod, B, ctx.dev)
     d = np.load(os.path.join(ROOT, "tests", "golden", "reversi_random_games.npz"))["rows"]
     d = d[d[:, 1] == 8]
     idx = np.arange(B) % len(d)  # positions sampled from fixture F1, tiled to the batch
-    own = torch.as_tensor(d[idx, 4].copy().view(np.int64)).to(dev)
-    opp = torch.as_tensor(d[idx, 5].copy().view(np.int64)).to(dev)
+    own = torch.as_tensor(d[idx, 4].copy().view(np.int64)).to(ctx.dev)
+    opp = torch.as_tensor(d[idx, 5].copy().view(np.int64)).to(ctx.dev)
     L = _lib.lib()
     for _ in range(W):
         net.forward(own, opp, fp8=fp8)
-    L.bz_profile_reset(); L.bz_profile_enable(1)
-    torch.cuda.synchronize()
+    L.bz_profile_reset()
+    L.bz_profile_reserve(_lib.PROF_SLOTS.index("tower"), K + 8)
+    L.bz_profile_enable(1)
+    ctx.barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         net.forward(own, opp, fp8=fp8)
-    torch.cuda.synchronize()
+    ctx.barrier()
     dt = time.perf_counter() - t0
     L.bz_profile_enable(0)
     launches, timed, ms = _lib.profile_read()["tower"]
-    avg_ms = ms / max(timed, 1)
+    assert launches == timed == K, (launches, timed, K)
+    avg_ms = ms / timed
     peak = 2 * MFMA_PEAK_TFLOPS if fp8 else MFMA_PEAK_TFLOPS
     ach = B * NET_FLOP_PER_POS / (avg_ms * 1e-3) / 1e12
-    if rank == 0:
-        print(json.dumps({"metric": "net_leaf_evals_per_s", "value": B * K * world / dt, "unit": "evals/s", "n_gpus": world,
-                          "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if fp8 else "bf16", "data": "synthetic",
-                          "config": {"workload": f"reversi8x8_net_forward_batch{B}_{'fp8' if fp8 else 'bf16'}",
-                                     "positions": "fixture F1 positions tiled to the batch"},
-                          "roofline": {"bound": "mfma", "kernel": "f8::k_tower_fp8" if fp8 else "k_tower_bf16",
-                                       "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                       "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
-                                       "flop_per_launch": B * NET_FLOP_PER_POS}}))
+    prec = "fp8" if fp8 else "bf16"
+    return {"metric": "net_leaf_evals_per_s", "value": B * K * ctx.world / dt, "unit": "evals/s", "n_gpus": ctx.world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": f"reversi8x8_net_forward_batch{B}_{prec}",
+                       "positions": "fixture F1 positions tiled to the batch"},
+            "roofline": {"bound": "mfma", "kernel": "f8::k_tower_fp8" if fp8 else "k_tower_bf16", "achieved": ach,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": launches,
+                         "avg_launch_ms": avg_ms, "flop_per_launch": B * NET_FLOP_PER_POS}}
+
+
+def run_ttt(ctx, B, sims, K, W):
+    """BASELINE cfg 2: TTT, uniform priors, the whole search of a move is one fused tree kernel"""
+    from betazero_amd import _lib
+    from betazero_amd.engine import SelfPlayEngine
+    L = _lib.lib()
+    eng = SelfPlayEngine("ttt", B, sims, "uniform", game_id_base=ctx.rank * B, game_id_stride=ctx.world * B,
+                         device=ctx.dev)
+
+    def step():
+        eng.reset_games()
+        for _ in range(9):  # a TTT game has at most 9 moves; finished slots idle
+            eng.search()
+            eng.play(False)
+    for _ in range(W):
+        step()
+    ctx.sync()
+    eng.reset_counters()
+    L.bz_profile_reset()
+    L.bz_profile_reserve(_lib.PROF_SLOTS.index("search_fused"), 9 * K + 8)
+    L.bz_profile_enable(1)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    L.bz_profile_enable(0)
+    eng.status()  # raises on engine error flags
+    cnt = eng.counters()
+    launches, timed, ms = _lib.profile_read()["search_fused"]
+    assert launches == timed
+    avg_ms = ms / max(timed, 1)
+    tb = tree_bytes(cnt)
+    ach = tb / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+    return {"metric": "selfplay_games_per_s", "value": K * B * ctx.world / dt, "unit": "games/s", "n_gpus": ctx.world,
+            "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "data": "synthetic", "dtype": "u64+f32",
+            "config": {"workload": f"ttt3x3_{B}games_{sims}sims_uniform_tree_only", "games_per_gpu": B,
+                       "sims_per_move": sims, "step": "one complete self-play iteration of all games"},
+            "roofline": {"bound": "hbm", "kernel": "k_search_fused<TicTacToe>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tb / max(launches, 1)},
+            "sims_per_s": cnt["n_sims"] * ctx.world / dt, "counters": cnt}
+
+
+def run_reversi(ctx, args, B, sims, K, W):
+    import torch
+    import torch.distributed as dist
+    from betazero_amd import _lib
+    from betazero_amd.distributed import all_gather_example_blocks
+    from betazero_amd.engine import SelfPlayEngine
+    from betazero_amd.net import DeviceNet, PolicyValueNet
+    L = _lib.lib()
+    prec = args.precision or "bf16"
+    torch.manual_seed(0)
+    mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
+    if prec == "fp8":
+        from betazero_amd.quant import fake_quantize_fp8_
+        fake_quantize_fp8_(mod)
+    net = DeviceNet.from_module(mod, B, ctx.dev)
+    rounds = 2 + (W + K) // 40
+    # NS independent pipelines of B/NS games, each on its own HIP stream: the tree step of one
+    # overlaps the net kernel of the other and their net launches fill each other's tail wave.
+    NS = max(1, args.streams)
+    assert B % NS == 0
+    Bs = B // NS
+    streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(NS)]
+    engs = [SelfPlayEngine("reversi", Bs, sims, "net_" + prec, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
+                           game_id_base=ctx.rank * B + i * Bs, game_id_stride=ctx.world * B, device=ctx.dev,
+                           stagger=PLIES_PER_GAME if args.mode == "steady" else 0) for i in range(NS)]
+    for e in engs:
+        e.reset_games()
+    ctx.sync()
+
+    def step():
+        if args.mode == "steady":
+            for e, st in zip(engs, streams):
+                with torch.cuda.stream(st):
+                    e.search()
+                    e.play(True)
+            return
+        for e, st in zip(engs, streams):  # one whole iteration: every game from its opening to the end
+            with torch.cuda.stream(st):
+                e.reset_games()
+        active = True
+        while active:
+            for e, st in zip(engs, streams):
+                with torch.cuda.stream(st):
+                    e.search()
+                    e.play(False)
+            ctx.sync()
+            active = any(e.status()[0] > 0 for e in engs)
+
+    for _ in range(W):
+        step()
+    ctx.sync()
+    fin0 = sum(e.status()[1] for e in engs)
+    for e in engs:
+        e.reset_counters()
+    L.bz_profile_reset()
+    prof_on = not args.no_kernel_timers
+    if prof_on and args.mode == "steady":  # events exist before the timed loop: it only records them
+        per = K * NS * (sims + 2) + 64
+        for slot in ("tower", "select", "expand_backup", "play"):
+            L.bz_profile_reserve(_lib.PROF_SLOTS.index(slot), per)
+    L.bz_profile_enable(1 if prof_on else 0)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    ctx.sync()
+    pooled_bytes = 0
+    if ctx.world > 1:  # the one exchange step: pool this iteration's (s, pi, z) -- ONE all-gather
+        blocks = [e.example_block() for e in engs]
+        if ctx.backend != "nccl":
+            blocks = [b.cpu() for b in blocks]
+        pooled, _ = all_gather_example_blocks(blocks)
+        pooled_bytes = int(pooled.numel())
+        del pooled
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    L.bz_profile_enable(0)
+    fin1 = sum(e.status()[1] for e in engs)  # status() raises on engine error flags
+    if args.mode == "iteration":
+        fin1, fin0 = K * B, 0
+    games = float(fin1 - fin0)
+    if ctx.world > 1:
+        t = torch.tensor([dt, games], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, games = float(tmax[0]), float(tsum[1])
+    cnt = {}
+    for e in engs:
+        for k, v in e.counters().items():
+            cnt[k] = cnt.get(k, 0) + v
+    if ctx.rank != 0:
+        return None
+    out = {"metric": "selfplay_games_per_s", "value": games / dt, "unit": "games/s", "n_gpus": ctx.world, "steps": K,
+           "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "data": "synthetic", "dtype": prec,
+           "config": {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{prec}",
+                      "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8, "openings": 12,
+                      "evaluator": "policy/value conv tower 6x128 (226.86 MFLOP per leaf), random init seed 0",
+                      "step": "one move for all concurrent games (steady-state pool, staggered starts)"
+                      if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",
+                      "pipelines": f"{NS} x {Bs} games on separate HIP streams",
+                      "parallelism": f"games sharded over {ctx.world} GPU(s), one all-gather of the example blocks"
+                                     + (f" ({pooled_bytes} bytes received per rank)" if pooled_bytes else "")}}
+    peak = MFMA_PEAK_TFLOPS if prec == "bf16" else 2 * MFMA_PEAK_TFLOPS  # dense fp8 = 5 PF
+    kname = ("k_tower_bf16" if prec == "bf16" else "f8::k_tower_fp8") + " (stem + 12 conv3x3 + heads, fused)"
+    if prof_on:
+        prof = _lib.profile_read()
+        launches, timed, ms = prof["tower"]
+        assert timed == launches, f"kernel-timer capacity exceeded ({timed} of {launches} launches timed)"
+        # leaves are packed before the net runs: a launch evaluates only the non-terminal leaves
+        flop_per_launch = cnt["n_net_leaves"] / max(launches, 1) * NET_FLOP_PER_POS  # stem+tower+heads = ONE kernel
+        union_ms, sum_ms = _lib.profile_union_ms("tower")
+        ach = flop_per_launch * launches / (union_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": None, "launches": launches, "flop_per_launch": flop_per_launch,
+            "positions_per_launch": cnt["n_net_leaves"] / max(launches, 1),
+            # the NS pipelines' launches overlap on the chip, so a launch's own event-to-event duration is
+            # SHARED time.  `achieved` = flop_per_launch x launches / busy_ms, busy_ms = union of all launch
+            # intervals (every launch timed, nothing extrapolated); avg_launch_ms = busy_ms / launches is the
+            # chip time one launch costs.  The shared-time view is kept beside it.
+            "busy_ms": union_ms, "avg_launch_ms": union_ms / max(launches, 1),
+            "shared_time": {"avg_launch_ms": sum_ms / max(launches, 1), "concurrent_launches": sum_ms / union_ms,
+                            "tflops_per_launch": flop_per_launch / (sum_ms / max(launches, 1) * 1e-3) / 1e12}}
+        for path in PMC_TRAFFIC:
+            try:
+                tr = json.load(open(os.path.join(ROOT, path)))["k_tower_bf16"]
+                if prec == "bf16":
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({path}: " \
+                                                        f"{tr.get('positions_per_launch', 4096)} positions per launch)"
+                break
+            except Exception:
+                continue
+        tb = tree_bytes(cnt)
+        t_union, t_sum = _lib.profile_union_ms("select")
+        out["roofline_tree"] = {"bound": "hbm", "kernels": "k_tree_step (expand + backup + select, 16 lanes per game)",
+                                "achieved": tb / (t_sum * 1e-3) / 1e9 if t_sum else None, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": tb / (t_sum * 1e-3) / 1e9 / HBM_PEAK_GBS if t_sum else None,
+                                "algorithmic_bytes": tb, "kernel_ms": t_sum, "launches": prof["select"][0],
+                                "note": "latency-bound pointer chase, overlapped with the other pipeline's net launch"}
+        out["kernel_ms_total"] = {k: round(v[2], 3) for k, v in prof.items() if v[0]}
+    else:
+        out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": cnt["n_net_leaves"] * NET_FLOP_PER_POS / dt / 1e12,
+                           "peak": peak, "unit": "TFLOP/s", "frac": cnt["n_net_leaves"] * NET_FLOP_PER_POS / dt / 1e12 / peak,
+                           "traffic": None, "note": "--no-kernel-timers: whole-run flops / wall time (lower bound)"}
+    out["sims_per_s"] = cnt["n_sims"] * ctx.world / dt
+    out["net_evals_per_s"] = cnt["n_net_leaves"] * ctx.world / dt
+    out["net_tflops_e2e"] = cnt["n_net_leaves"] * ctx.world * NET_FLOP_PER_POS / dt / 1e12
+    out["counters"] = cnt
+    return out
 
 
 def main():
@@ -143,216 +457,95 @@ def main():
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"],
-                    help="net precision; bf16 is the BASELINE config, fp8 (e4m3, cfg 5 kernel) is a supplementary line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short cfg-2 / cfg-5 runs after the headline one")
+    ap.add_argument("--no-kernel-timers", action="store_true",
+                    help="leave the in-library HIP-event timers off (A/B of their cost on `value`)")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp8"],
+                    help="net precision; default bf16 for the self-play workload (the BASELINE config; fp8 is a "
+                         "supplementary line) and fp8 for --workload net (cfg 5)")
     ap.add_argument("--mode", default="steady", choices=["steady", "iteration"],
                     help="reversi: steady = one move per step on a staggered pool (default); iteration = a step is a\n"
                          "complete self-play iteration from the start position to the last finished game (cross-check)")
     ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
     args = ap.parse_args()
 
-    import numpy as np
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: start me as "
+                 f"`python bench.py --gpus N` or under torchrun with --nproc-per-node equal to --gpus")
+
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx = Ctx()
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("BZ_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU
-    local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
+    ctx.backend = os.environ.get("BZ_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on one GPU / on CPU
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        if os.environ.get("BZ_BENCH_REHEARSAL") != "1" or ctx.world < 2:
+            sys.exit("bench.py: no GPU visible (the engine has no CPU path; BZ_BENCH_REHEARSAL=1 with --gpus >= 2 "
+                     "rehearses the multi-rank plumbing only)")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(backend)
-    n_gpus = world
-    dev = f"cuda:{local}"
+        dist.init_process_group("gloo")
+        rehearsal(args, ctx.rank, ctx.world)
+        dist.destroy_process_group()
+        return
+    local = local % n_dev
+    ctx.dev = f"cuda:{local}"
     torch.cuda.set_device(local)
-
-    from betazero_amd import _lib
-    from betazero_amd.distributed import all_gather_example_tensors
-    from betazero_amd.engine import SelfPlayEngine
-    from betazero_amd.net import DeviceNet, PolicyValueNet
-    _lib.require_gpu()
-    L = _lib.lib()
-
-    if args.workload == "net":  # BASELINE cfg 5: leaf-eval batch 8192, fp8 e4m3 net, MFMA-utilisation run
-        return bench_net_only(args, rank, world, dev)
-    reversi = args.workload == "reversi"
-    B = args.games or (4096 if reversi else 65536)
-    sims = args.sims or (800 if reversi else 50)
-    K = args.steps if args.steps is not None else (8 if reversi else 20)
-    W = args.warmup if args.warmup is not None else (1 if reversi else 2)
+    if ctx.world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if ctx.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(ctx.dev))
+        else:
+            dist.init_process_group(ctx.backend)
+        assert dist.get_world_size() == args.gpus
+    ctx.sync = torch.cuda.synchronize
 
     def barrier():
-        if world > 1:
+        if ctx.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    ctx.barrier = barrier
 
-    if reversi:
-        torch.manual_seed(0)
-        mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
-        if args.precision == "fp8":
-            from betazero_amd.quant import fake_quantize_fp8_
-            fake_quantize_fp8_(mod)
-        net = DeviceNet.from_module(mod, B, dev)
-        rounds = 2 + (W + K) // 40
-        # NS independent pipelines of B/NS games, each on its own HIP stream: the tree step of one
-        # overlaps the net kernel of the other and their net launches fill each other's tail wave.
-        NS = max(1, args.streams)
-        assert B % NS == 0
-        Bs = B // NS
-        streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-        engs = [SelfPlayEngine("reversi", Bs, sims, "net_" + args.precision, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
-                               game_id_base=rank * B + i * Bs, game_id_stride=world * B, device=dev,
-                               stagger=PLIES_PER_GAME if args.mode == "steady" else 0) for i in range(NS)]
-        eng = engs[0]
-        for e in engs:
-            e.reset_games()
-        torch.cuda.synchronize()
+    from betazero_amd import _lib
+    _lib.require_gpu()
 
-        def step():
-            if args.mode == "steady":
-                for e, st in zip(engs, streams):
-                    with torch.cuda.stream(st):
-                        e.search()
-                        e.play(True)
-                return
-            for e, st in zip(engs, streams):  # one whole iteration: every game from its opening to the end
-                with torch.cuda.stream(st):
-                    e.reset_games()
-            active = True
-            while active:
-                for e, st in zip(engs, streams):
-                    with torch.cuda.stream(st):
-                        e.search()
-                        e.play(False)
-                torch.cuda.synchronize()
-                active = any(e.status()[0] > 0 for e in engs)
+    if args.workload == "net":  # BASELINE cfg 5: leaf-eval batch 8192, fp8 e4m3 net, MFMA-utilisation run
+        out = run_net(ctx, args.games or 8192, args.steps if args.steps is not None else 1000,
+                      args.warmup if args.warmup is not None else 50, (args.precision or "fp8") == "fp8")
+    elif args.workload == "ttt":
+        sims = args.sims or 50
+        out = run_ttt(ctx, args.games or 65536, sims, args.steps if args.steps is not None else 20,
+                      args.warmup if args.warmup is not None else 2)
+        if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_ttt(sims)
     else:
-        eng = SelfPlayEngine("ttt", B, sims, "uniform", game_id_base=rank * B, game_id_stride=world * B, device=dev)
-        engs = [eng]
-
-        def step():
-            eng.reset_games()
-            for _ in range(9):  # a TTT game has at most 9 moves; finished slots idle
-                eng.search()
-                eng.play(False)
-
-    for _ in range(W):
-        step()
-    torch.cuda.synchronize()
-    fin0 = sum(e.status()[1] for e in engs)
-    for e in engs:
-        e.reset_counters()
-    L.bz_profile_reset()
-    L.bz_profile_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:  # the one exchange step: pool this iteration's (s, pi, z)
-        for e in engs:
-            t = e.example_tensors()
-            if backend != "nccl":
-                t = {k: v.cpu() for k, v in t.items()}
-            pooled = all_gather_example_tensors(t)
-            del pooled
-    barrier()
-    dt = time.perf_counter() - t0
-    L.bz_profile_enable(0)
-    fin1 = sum(e.status()[1] for e in engs)
-    if not reversi or args.mode == "iteration":
-        fin1, fin0 = K * B, 0
-    games = float(fin1 - fin0)
-    if world > 1:
-        t = torch.tensor([dt, games], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, games = float(tmax[0]), float(tsum[1])
-    cnt = {}
-    for e in engs:
-        for k, v in e.counters().items():
-            cnt[k] = cnt.get(k, 0) + v
-    prof = _lib.profile_read()
-
-    if rank == 0:
-        out = {"metric": "selfplay_games_per_s", "value": games / dt, "unit": "games/s", "n_gpus": n_gpus, "steps": K,
-               "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "data": "synthetic"}
-        if reversi:
-            out["dtype"] = args.precision
-            out["config"] = {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{args.precision}",
-                             "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8,
-                             "openings": 12, "evaluator": "policy/value conv tower 6x128 (226.86 MFLOP per leaf), random init seed 0",
-                             "step": "one move for all concurrent games (steady-state pool, staggered starts)"
-                             if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",
-                             "pipelines": f"{NS} x {Bs} games on separate HIP streams",
-                             "parallelism": f"games sharded over {n_gpus} GPU(s), one all-gather of examples"}
-            launches, timed, ms = prof["tower"]
-            avg_ms = ms / max(timed, 1)
-            # leaves are packed before the net runs: a launch evaluates only the non-terminal leaves
-            pos_per_launch = cnt["n_net_leaves"] / max(launches, 1)
-            flop_per_launch = pos_per_launch * NET_FLOP_PER_POS  # stem + tower + heads are ONE kernel
-            ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
-            peak = MFMA_PEAK_TFLOPS if args.precision == "bf16" else 2 * MFMA_PEAK_TFLOPS  # dense fp8 = 5 PF
-            union_ms, sum_ms = _lib.profile_union_ms("tower")
-            conc = sum_ms / union_ms if union_ms else 1.0
-            chip = cnt["n_net_leaves"] * NET_FLOP_PER_POS * (timed / max(launches, 1)) / (union_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": ("k_tower_bf16" if args.precision == "bf16" else "f8::k_tower_fp8") +
-                               " (stem + 12 conv3x3 + heads, fused)",
-                               "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "launches": launches,
-                               "avg_launch_ms": avg_ms, "positions_per_launch": pos_per_launch,
-                               "flop_per_launch": flop_per_launch,
-                               # launches of the NS pipelines overlap on the chip: per-launch duration is
-                               # shared time.  chip-level = flops of all launches / union of their intervals
-                               "concurrent_launches": conc, "achieved_chip": chip,
-                               "frac_chip": chip / peak,
-                               "note": "achieved/frac are per launch as specified (flops of one launch / its mean "
-                                       "duration); with --streams 2 two launches share the chip, so each launch's "
-                                       "duration is shared time: achieved_chip = flops of all launches / union of "
-                                       "their intervals is the chip-level rate (--streams 1 makes the two coincide)"}
-            try:
-                assert args.precision == "bf16"
-                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["k_tower_bf16"]
-                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes at 4096 positions per launch (profiles/r01_pmc_traffic.json)"
-            except Exception:
-                pass
-            tb = tree_bytes(cnt)
-            tree_ms = prof["select"][2] * prof["select"][0] / max(prof["select"][1], 1) + \
-                prof["expand_backup"][2] * prof["expand_backup"][0] / max(prof["expand_backup"][1], 1)
-            out["roofline_tree"] = {"bound": "hbm", "kernels": "k_tree_step (expand + backup + select, 16 lanes per game)",
-                                    "achieved": tb / (tree_ms * 1e-3) / 1e9 if tree_ms else None,
-                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": tb / (tree_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tree_ms else None,
-                                    "algorithmic_bytes": tb, "kernel_ms": tree_ms}
-            out["sims_per_s"] = cnt["n_sims"] * world / dt
-            out["net_evals_per_s"] = cnt["n_net_leaves"] * world / dt
-            out["net_tflops_e2e"] = cnt["n_net_leaves"] * world * NET_FLOP_PER_POS / dt / 1e12
-            out["kernel_ms_total"] = {k: round(v[2] * v[0] / max(v[1], 1), 3) for k, v in prof.items() if v[0]}
-        else:
-            out["dtype"] = "u64+f32"
-            out["config"] = {"workload": "ttt3x3_65536games_50sims_uniform_tree_only" if (B, sims) == (65536, 50)
-                             else f"ttt3x3_{B}games_{sims}sims_uniform_tree_only", "games_per_gpu": B,
-                             "sims_per_move": sims, "step": "one complete self-play iteration of all games"}
-            launches, timed, ms = prof["search_fused"]
-            avg_ms = ms / max(timed, 1)
-            tb = tree_bytes(cnt)
-            ach = tb / max(launches, 1) / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_search_fused<TicTacToe>", "achieved": ach,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                               "launches": launches, "avg_launch_ms": avg_ms,
-                               "algorithmic_bytes_per_launch": tb / max(launches, 1)}
-            out["sims_per_s"] = cnt["n_sims"] * world / dt
-        out["counters"] = cnt
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_reversi(sims) if reversi else cpu_baseline_ttt(sims)  # bf16-emulating oracle
+        sims = args.sims or 800
+        out = run_reversi(ctx, args, args.games or 4096, sims, args.steps if args.steps is not None else 8,
+                          args.warmup if args.warmup is not None else 1)
+        if ctx.rank == 0 and ctx.world == 1:
+            if not args.no_secondary:  # cfg 2 and cfg 5 in the same driver-timed process (a few seconds)
+                sec = {}
+                for name, fn in (("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
+                                 ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True))):
+                    try:
+                        r = fn()
+                        sec[name] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config",
+                                                       "roofline")}
+                    except Exception as e:
+                        sec[name] = {"error": repr(e)}
+                out["secondary"] = sec
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_reversi(sims)
+    if ctx.rank == 0:
+        out["n_gpus"] = dist.get_world_size() if ctx.world > 1 else 1
+        assert out["n_gpus"] == args.gpus
         print(json.dumps(out))
-    if world > 1:
+    if ctx.world > 1:
         dist.destroy_process_group()
 
 

@@ -4,7 +4,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libbz_hip.so")
+# BZ_HIP_SO: load a diagnostic variant built by betazero_amd.build.build_variant() instead of the
+# product library (needs BZ_ALLOW_EXPERIMENT=1 as well: such builds may time but not compute)
+SO = os.environ.get("BZ_HIP_SO") or os.path.join(HERE, "libbz_hip.so")
+ABI_VERSION = 2
 
 BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
 GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3
@@ -28,12 +31,13 @@ class EngineLayout(C.Structure):
     _fields_ = [(n, i64) for n in ("ex_own", "ex_opp", "ex_pi", "ex_z", "ex_mover", "ex_act", "ex_len", "ex_winner",
                                    "root_N", "root_W", "root_P", "leaf_own", "leaf_opp", "leaf_kind", "logits",
                                    "value", "g_own", "g_opp", "g_to_move", "g_state", "counters")] + \
-               [("na", i32), ("t_max", i32)]
+               [("na", i32), ("t_max", i32)] + [(n, i64) for n in ("ex_begin", "ex_bytes", "ex_meta")]
 
 
 _SIGS = {
     "bz_abi_version": (i32, []),
     "bz_last_error": (C.c_char_p, []),
+    "bz_build_info": (C.c_char_p, []),
     "bz_device_count": (i32, []),
     "bz_reversi_legal": (i32, [u64, u64, i32, C.POINTER(u64)]),
     "bz_reversi_apply": (i32, [u64, u64, i32, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
@@ -45,6 +49,7 @@ _SIGS = {
     "bz_reversi_step_batch": (i32, [vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
     "bz_reversi_step_batch_sized": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
     "bz_reversi_legal_batch": (i32, [vp, vp, i64, vp, vp]),
+    "bz_reversi_score_batch": (i32, [vp, vp, i64, vp, vp, vp]),
     "bz_ttt_step_batch": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
     "bz_augment_d4_batch": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "bz_net_update": (i32, [vp, vp, vp]),
@@ -76,6 +81,7 @@ _SIGS = {
     "bz_engine_reset_counters": (i32, [vp, vp]),
     "bz_engine_sum_counters": (i32, [vp, vp]),
     "bz_profile_enable": (i32, [i32]),
+    "bz_profile_reserve": (i32, [i32, i64]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),
     "bz_profile_reset": (i32, []),
     "bz_profile_intervals": (i32, [i32, vp, vp, i64, C.POINTER(i64)]),
@@ -100,8 +106,13 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.bz_abi_version() != 1:
-            raise RuntimeError("libbz_hip.so ABI version mismatch")
+        if L.bz_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{SO}: ABI version {L.bz_abi_version()}, expected {ABI_VERSION} -- rebuild it "
+                               "(python -m betazero_amd.build)")
+        info = (L.bz_build_info() or b"").decode()
+        if info != "product" and os.environ.get("BZ_ALLOW_EXPERIMENT") != "1":
+            raise RuntimeError(f"{SO} was built with [{info}], not the product flags; refusing to load it "
+                               "(set BZ_ALLOW_EXPERIMENT=1 for a diagnostic run)")
         _lib = L
     return _lib
 
@@ -134,7 +145,7 @@ def profile_read():
     return out
 
 
-def profile_union_ms(slot_name, cap=20000):
+def profile_union_ms(slot_name, cap=1 << 18):
     """(union busy time, summed duration) in ms of a slot's timed launches (they may overlap across streams)"""
     import numpy as np
     st = np.zeros(cap, np.float64)

@@ -27,14 +27,15 @@ def augment_examples(ex, dedupe=True, device="cuda:0"):
     act1 = torch.zeros((n, na), dtype=torch.float32, device=dev)
     act1[torch.arange(n, device=dev), torch.as_tensor(ex.act.astype(np.int64)).to(dev)] = 1.0
     act8 = torch.empty((8 * n, na), dtype=torch.float32, device=dev)
-    scratch = torch.empty(8 * n, dtype=torch.int64, device=dev)
+    scr_a = torch.empty(8 * n, dtype=torch.int64, device=dev)  # two distinct buffers: the kernel's outputs
+    scr_b = torch.empty(8 * n, dtype=torch.int64, device=dev)  # are __restrict__
     with torch.cuda.device(dev):
         st = torch.cuda.current_stream().cuda_stream
         L = _lib.lib()
         _lib.check(L.bz_augment_d4_batch(own.data_ptr(), opp.data_ptr(), pi.data_ptr(), n, size, na, own8.data_ptr(),
                                          opp8.data_ptr(), pi8.data_ptr(), key8.data_ptr(), st))
         _lib.check(L.bz_augment_d4_batch(own.data_ptr(), opp.data_ptr(), act1.data_ptr(), n, size, na,
-                                         scratch.data_ptr(), scratch.data_ptr(), act8.data_ptr(), None, st))
+                                         scr_a.data_ptr(), scr_b.data_ptr(), act8.data_ptr(), None, st))
     keep = torch.arange(8 * n, device=dev)
     if dedupe:  # first occurrence of every distinct row, insertion order preserved
         sk, order = torch.sort(key8, stable=True)

@@ -1,5 +1,13 @@
-"""Build recipe for libbz_hip.so (gfx950 only; hipcc cross-compiles without a GPU)."""
+"""Build recipe for libbz_hip.so (gfx950 only; hipcc cross-compiles without a GPU).
+
+The product library is always built with exactly FLAGS: nothing from the environment reaches its
+compile line.  Diagnostic variants (in-kernel stamps, ...) are built by build_variant() into a
+SEPARATE file, libbz_hip.<name>.so, and are only ever loaded when BZ_HIP_SO points at them
+(betazero_amd/_lib.py); they never overwrite the product library.  The flag set a library was
+built with is compiled into it (bz_build_info()) and a hash of it sits next to the .so, so a
+library built with other flags is stale no matter what its mtime says."""
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -18,22 +26,59 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def stale():
-    if not os.path.exists(SO):
+def _flag_hash(extra):
+    return hashlib.sha256(" ".join(FLAGS + list(extra)).encode()).hexdigest()[:16]
+
+
+def variant_path(name):
+    return os.path.join(HERE, f"libbz_hip.{name}.so")
+
+
+def stale(so=SO, extra=()):
+    if not os.path.exists(so):
         return True
-    t = os.path.getmtime(SO)
+    try:
+        if open(so + ".flags").read().strip() != _flag_hash(extra):
+            return True
+    except OSError:
+        return True
+    t = os.path.getmtime(so)
     return any(os.path.getmtime(p) > t for p in DEPS if os.path.exists(p))
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
-        return SO
-    cmd = [hipcc()] + FLAGS + os.environ.get("BZ_EXTRA_HIPCC_FLAGS", "").split() + ["-o", SO] + SRC
+def _compile(so, extra, verbose):
+    info = " ".join(f for f in list(extra) if f.startswith("-D")) or "product"
+    cmd = [hipcc()] + FLAGS + list(extra) + [f'-DBZ_BUILD_INFO="{info}"', "-o", so + ".tmp"] + SRC
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return SO
+    os.replace(so + ".tmp", so)  # an interrupted compile leaves the old library in place
+    with open(so + ".flags", "w") as f:
+        f.write(_flag_hash(extra) + "\n")
+    return so
+
+
+def build(force=False, verbose=False):
+    """the product library: fixed flags, nothing taken from the environment"""
+    if not force and not stale():
+        return SO
+    return _compile(SO, (), verbose)
+
+
+def build_variant(name, extra_flags, force=False, verbose=False):
+    """a diagnostic variant (e.g. name="stamps", extra_flags=["-DBZ_EXP_STAMPS"]) in its own file;
+    load it with BZ_HIP_SO=<path> BZ_ALLOW_EXPERIMENT=1"""
+    assert name and name != "so"
+    extra = ["-DBZ_EXPERIMENT"] + list(extra_flags)
+    so = variant_path(name)
+    if not force and not stale(so, extra):
+        return so
+    return _compile(so, extra, verbose)
 
 
 if __name__ == "__main__":
-    build(force=True, verbose=True)
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:], force=True, verbose=True))
+    else:
+        build(force=True, verbose=True)

@@ -4,6 +4,8 @@
 // pure 64-bit integer ALU (bz_rules.h) -- HBM-bound at 34+8 B per env step.
 #include <stdarg.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "bz_common.h"
@@ -21,41 +23,61 @@ void set_error(const char* fmt, ...) {
 
 namespace bz {
 namespace {
-constexpr int kProfCap = 16384;
+// In-library kernel timers.  Every launch of a slot carries a start and an end event on its own
+// stream; events are created up front by bz_profile_reserve() (so that nothing but the two
+// hipEventRecord calls sits in a timed loop) and grown on demand otherwise.  A slot holds at most
+// kProfCap launches -- bench.py's default run records about 32 k per slot.
+constexpr int kProfCap = 1 << 18;
 struct ProfSlot { std::vector<hipEvent_t> ev; int64_t launches = 0; int used = 0; };
 ProfSlot g_prof[BZ_PROF_N];
-bool g_prof_on = false;
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;  // launches may come from several host threads (one per stream)
+bool prof_grow(ProfSlot& p, int n_launches) {
+    while ((int)p.ev.size() < 2 * n_launches) {
+        hipEvent_t a;
+        if (hipEventCreate(&a) != hipSuccess) { (void)hipGetLastError(); return false; }
+        p.ev.push_back(a);
+    }
+    return true;
+}
 }  // namespace
 int prof_begin(int slot, hipStream_t s) {
-    if (!g_prof_on) return -1;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return -1;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfSlot& p = g_prof[slot];
     p.launches++;
-    if (p.used >= kProfCap) return -1;
-    if ((int)p.ev.size() < 2 * (p.used + 1)) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
-        p.ev.push_back(a); p.ev.push_back(b);
-    }
+    if (p.used >= kProfCap || !prof_grow(p, p.used + 1)) return -1;
     int idx = p.used++;
     (void)hipEventRecord(p.ev[2 * idx], s);
     return idx;
 }
 void prof_end(int slot, int idx, hipStream_t s) {
-    if (idx >= 0) (void)hipEventRecord(g_prof[slot].ev[2 * idx + 1], s);
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].ev[2 * idx + 1], s);
 }
 }  // namespace bz
 
 using namespace bz;
 
-BZ_EXPORT int32_t bz_profile_enable(int32_t on) { bz::g_prof_on = on != 0; return BZ_OK; }
+BZ_EXPORT int32_t bz_profile_enable(int32_t on) { bz::g_prof_on.store(on != 0); return BZ_OK; }
+BZ_EXPORT int32_t bz_profile_reserve(int32_t slot, int64_t n_launches) {
+    BZ_REQUIRE(slot >= 0 && slot < BZ_PROF_N && n_launches >= 0, "bz_profile_reserve: bad arguments");
+    std::lock_guard<std::mutex> lk(bz::g_prof_mu);
+    int n = (int)(n_launches < bz::kProfCap ? n_launches : bz::kProfCap);
+    if (!bz::prof_grow(bz::g_prof[slot], n)) { set_error("bz_profile_reserve: hipEventCreate failed"); return BZ_EHIP; }
+    return BZ_OK;
+}
 BZ_EXPORT int32_t bz_profile_reset(void) {
     (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(bz::g_prof_mu);
     for (auto& p : bz::g_prof) { p.launches = 0; p.used = 0; }
     return BZ_OK;
 }
 BZ_EXPORT int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* timed, double* total_ms) {
     BZ_REQUIRE(slot >= 0 && slot < BZ_PROF_N && launches && timed && total_ms, "bz_profile_read: bad arguments");
     BZ_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(bz::g_prof_mu);
     bz::ProfSlot& p = bz::g_prof[slot];
     double tot = 0;
     for (int i = 0; i < p.used; ++i) {
@@ -72,6 +94,7 @@ BZ_EXPORT int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* time
 BZ_EXPORT int32_t bz_profile_intervals(int32_t slot, double* starts_ms, double* ends_ms, int64_t cap, int64_t* n) {
     BZ_REQUIRE(slot >= 0 && slot < BZ_PROF_N && starts_ms && ends_ms && n, "bz_profile_intervals: bad arguments");
     BZ_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(bz::g_prof_mu);
     bz::ProfSlot& p = bz::g_prof[slot];
     int64_t m = p.used < cap ? p.used : cap;
     for (int64_t i = 0; i < m; ++i) {
@@ -84,6 +107,10 @@ BZ_EXPORT int32_t bz_profile_intervals(int32_t slot, double* starts_ms, double* 
     return BZ_OK;
 }
 
+#ifndef BZ_BUILD_INFO
+#define BZ_BUILD_INFO "unknown"
+#endif
+BZ_EXPORT const char* bz_build_info(void) { return BZ_BUILD_INFO; }
 BZ_EXPORT int32_t bz_abi_version(void) { return BZ_ABI_VERSION; }
 BZ_EXPORT const char* bz_last_error(void) { return bz::g_err; }
 BZ_EXPORT int32_t bz_device_count(void) {
@@ -220,6 +247,16 @@ __global__ void __launch_bounds__(256) k_reversi_legal(const u64* __restrict__ o
         legal[i] = rev_legal8(own[i], opp[i]);
 }
 
+// get_score for n boards (reversi_board.py:67-85): winner = sign(n_x - n_o) and the two counts
+__global__ void __launch_bounds__(256) k_reversi_score(const u64* __restrict__ x, const u64* __restrict__ o, int64_t n,
+                                                       int8_t* __restrict__ winner, uint8_t* __restrict__ counts) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int cx = popc64(x[i]), co = popc64(o[i]);
+        winner[i] = (int8_t)(cx > co ? 1 : (co > cx ? -1 : 0));
+        reinterpret_cast<uchar2*>(counts)[i] = make_uchar2((unsigned char)cx, (unsigned char)co);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ttt_step(const uint16_t* __restrict__ own, const uint16_t* __restrict__ opp,
                                                   const uint8_t* __restrict__ action, const int8_t* __restrict__ to_move,
                                                   int64_t n, uint16_t* __restrict__ own_next,
@@ -331,6 +368,15 @@ BZ_EXPORT int32_t bz_reversi_legal_batch(const uint64_t* own, const uint64_t* op
     if (n == 0) return BZ_OK;
     hipLaunchKernelGGL(k_reversi_legal, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, own, opp, n, legal);
     BZ_LAUNCH_CHECK("k_reversi_legal");
+    return BZ_OK;
+}
+BZ_EXPORT int32_t bz_reversi_score_batch(const uint64_t* x, const uint64_t* o, int64_t n, int8_t* winner, uint8_t* counts,
+                                         void* stream) {
+    BZ_REQUIRE(n >= 0 && x && o && winner && counts, "bz_reversi_score_batch: null pointer");
+    BZ_REQUIRE(((uintptr_t)counts & 1) == 0, "bz_reversi_score_batch: counts must be 2-byte aligned");
+    if (n == 0) return BZ_OK;
+    hipLaunchKernelGGL(k_reversi_score, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, o, n, winner, counts);
+    BZ_LAUNCH_CHECK("k_reversi_score");
     return BZ_OK;
 }
 BZ_EXPORT int32_t bz_ttt_step_batch(const uint16_t* own, const uint16_t* opp, const uint8_t* action,

@@ -85,6 +85,12 @@ __global__ void __launch_bounds__(256) k_sum_counters(EngineDev E) {
     }
 }
 
+// Orders a lane group's earlier stores (edges / node header written by dev_expand, child node
+// written by dev_select) before its later loads of the same addresses.  All communication is
+// between lanes of ONE wave (a game's G::GW lanes), which share the CU's L1, so workgroup scope
+// is enough; acq_rel so that neither the stores nor the following loads may move across it.
+__device__ __forceinline__ void group_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
 // logits source for the expansion of one leaf
 struct LogitSrc {
     int kind; u64 h; const float* row;
@@ -386,7 +392,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
         if (do_select) {
             uint8_t kind8 = LEAF_NONE;
             if (active) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // edges written above are read below
+                group_fence();  // edges written above are read below
                 u32 nn = E.n_nodes[g], leaf; int k2, depth; float tv;
                 dev_select<G>(E, g, sub, sim_idx, nn, leaf, k2, depth, tv, c);
                 const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
@@ -427,14 +433,14 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
             LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
             const u64 rown = E.g_own[g], ropp = E.g_opp[g];
             ls.h = hash_pos(rown, ropp);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            group_fence();
             dev_expand<G>(E, g, sub, 0, G::legal(rown, ropp), ls, ne, c);
             for (int s = 0; s < E.sims; ++s) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this group's stores -> its loads
+                group_fence();  // this group's stores -> its loads
                 u32 leaf; int kind, depth; float v;
                 dev_select<G>(E, g, sub, (u32)s, nn, leaf, kind, depth, v, c);
                 if (kind == LEAF_EVAL) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    group_fence();
                     const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
                     u64 lo = nd->own, lp = nd->opp;
                     ls.h = hash_pos(lo, lp);
@@ -553,7 +559,7 @@ struct Carver {
 struct Offsets {
     int64_t nodes, edges, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
         path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
-        ex_act, ex_len, ex_winner, root_N, root_W, root_P, counters, cnt_slots, flags, total;
+        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, total;
     int n_cnt_slots;
     int ncap, ecap, na, maxd;
 };
@@ -585,6 +591,8 @@ Offsets carve(const bz_engine_cfg& c) {
     o.ex_own = k.take(R * B * T * 8); o.ex_opp = k.take(R * B * T * 8); o.ex_pi = k.take(R * B * T * o.na * 4);
     o.ex_z = k.take(R * B * T); o.ex_mover = k.take(R * B * T); o.ex_act = k.take(R * B * T);
     o.ex_len = k.take(R * B * 4); o.ex_winner = k.take(R * B);
+    // ex_own .. ex_meta are consecutive: ONE byte range [ex_own, ex_meta + 256) is what the all-gather ships
+    o.ex_meta = k.take(256);
     o.root_N = k.take(B * o.na * 4); o.root_W = k.take(B * o.na * 4); o.root_P = k.take(B * o.na * 4);
     o.counters = k.take(16 * 8);
     o.n_cnt_slots = (int)((B * 16 + 63) / 64) + 4;  // one slot per wave of the widest (group) launch
@@ -658,6 +666,17 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     l.root_P = o.root_P; l.leaf_own = o.leaf_own; l.leaf_opp = o.leaf_opp; l.leaf_kind = o.leaf_kind;
     l.logits = o.logits; l.value = o.value; l.g_own = o.g_own; l.g_opp = o.g_opp; l.g_to_move = o.g_to_move;
     l.g_state = o.g_state; l.counters = o.counters; l.na = o.na; l.t_max = cfg->t_max;
+    l.ex_begin = o.ex_own; l.ex_bytes = o.ex_meta + 256 - o.ex_own; l.ex_meta = o.ex_meta;
+    {   // self-describing header of the example block (so a gathered block can be unpacked without its engine)
+        uint64_t meta[32] = {0};
+        meta[0] = 0x425A455841000002ULL;  // "BZEXA" + layout version 2
+        meta[1] = cfg->game_id_base; meta[2] = cfg->game_id_stride; meta[3] = (uint64_t)cfg->n_games;
+        meta[4] = (uint64_t)cfg->rounds; meta[5] = (uint64_t)cfg->t_max; meta[6] = (uint64_t)o.na; meta[7] = (uint64_t)cfg->game;
+        const int64_t offs[8] = {o.ex_own, o.ex_opp, o.ex_pi, o.ex_z, o.ex_mover, o.ex_act, o.ex_len, o.ex_winner};
+        for (int i = 0; i < 8; ++i) meta[8 + i] = (uint64_t)(offs[i] - o.ex_own);
+        hipError_t me = hipMemcpy(at<char>(ws, o.ex_meta), meta, sizeof(meta), hipMemcpyHostToDevice);
+        if (me != hipSuccess) { delete e; return hip_fail(me, "bz_engine_create: example header upload"); }
+    }
     *out = e;
     return BZ_OK;
 }

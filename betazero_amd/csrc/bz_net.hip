@@ -41,7 +41,6 @@ struct bz_net {
     float *conv_w, *conv_b;          // [2NB][9][C][C] as [tap][ci][co]; [2NB][C]
     __bf16* conv_wf;                 // [2NB+pad][9][8][4][64][8] fragment-major (C == 128)
     __bf16 *stem_wf, *head_wf;       // [2][4][64][8], [8][64][8] fragments (C == 128)
-    __bf16 *conv_wf16, *stem_wf16, *head_wf16;  // 16x16x32 shape: [L*9+1][4][8][64][8], [8][64][8], [4][64][8]
     uint8_t *conv_wf8, *head_wf8;    // e4m3: [L*9+1][2][4][2][64][16], [2][2][64][16]
     float *dq8, *head_dq8, *ones;    // [L][128], [4], [128]
     float *pol_w, *pol_b, *polfc_wT, *polfc_b;  // [2][C], [2], [128][65], [65]
@@ -49,6 +48,10 @@ struct bz_net {
     // activations (device)
     float *act_a, *act_b;            // f32 parity path: [max_batch][64][C] x 2 (the MFMA paths keep activations in LDS)
     void* ws_base;
+    // the f32 parity path ping-pongs through act_a/act_b, which belong to the net: forwards issued on
+    // different streams are ordered through this event (the MFMA paths have no such scratch)
+    hipEvent_t f32_done;
+    bool f32_used;
 };
 
 namespace {
@@ -180,19 +183,17 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
 // ------------------------------------------------------------------ bf16 MFMA tower
 constexpr int kTC = 128;                  // channels
 constexpr int kTileBytes = 65 * 256;      // 64 cells x 256 B + one zero cell
-#ifndef BZ_TOWER_P
-#define BZ_TOWER_P 4
-#endif
-#ifndef BZ_TOWER_SHAPE
-#define BZ_TOWER_SHAPE 32   // MFMA shape of the fused net kernel: 32 (32x32x16) or 16 (16x16x32)
-#endif
-#ifndef BZ_LAST_TAP_TILE_MAJOR
-#define BZ_LAST_TAP_TILE_MAJOR 0
-#endif
-constexpr int kPosPerWG = BZ_TOWER_P;    // positions resident per workgroup (4: one WG per CU; 2: two WGs per CU)
+// positions resident per workgroup: 4 = one workgroup per CU.  (Round 1 measured the alternatives on one
+// device -- 2 positions x 2 workgroups per CU, a tile-major last tap, the 16x16x32 MFMA shape: all within
+// +-1 % because the kernel sits on the chip's power limit, DESIGN.md 5 -- and they were removed.)
+constexpr int kPosPerWG = 4;
 template <int P> constexpr int buf_bytes() { return P * kTileBytes; }
 template <int P> constexpr int tower_lds() { return 2 * P * kTileBytes; }
 
+// Diagnostic build only (tools/exp_stamps.sh -> a separate libbz_hip.stamps.so, never the product .so)
+#if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
+#endif
 #ifdef BZ_EXP_STAMPS
 __device__ unsigned long long g_dbg[8 * 4096];
 #define BZ_STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
@@ -223,11 +224,7 @@ __device__ __forceinline__ void load_b(bf16x8 (&b)[P][2], const char* in, const 
     for (int nt = 0; nt < 2; ++nt) {
         const char* bp = in + (boff[nt] ^ (kc << 5));
 #pragma unroll
-#ifdef BZ_EXP_NO_BLOAD
-        for (int p = 0; p < P; ++p) { asm volatile("" : "+v"(b[p][nt]) : "v"(bp)); }
-#else
         for (int p = 0; p < P; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * kTileBytes);
-#endif
     }
 }
 template <int P>
@@ -236,11 +233,7 @@ __device__ __forceinline__ void mfma8(f32x16 (&acc)[P][2], const bf16x8& a, cons
     for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-#ifdef BZ_EXP_NO_MFMA
-            { asm volatile("" :: "v"(a), "v"(b[p][nt])); }
-#else
             acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[p][nt], acc[p][nt], 0, 0, 0);
-#endif
 }
 
 // One conv tap = 8 k-steps of 8 MFMAs.  Weight fragments of this tap are in register
@@ -307,60 +300,6 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[P][2], char* out, bool se
         }
 }
 
-// epilogue of ONE accumulator tile (position p, cell tile nt)
-__device__ __forceinline__ void epilogue_tile(const f32x16& a, char* out, bool second, const f32x4 (&bq)[4], int p, int nt,
-                                              int w, int r, int h) {
-    const int cell = 32 * nt + r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int off = p * kTileBytes + cell_off(cell, 4 * w + q) + 8 * h;
-        f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-        v = v + bq[q];
-        if (second) {
-            bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
-            v = v + __builtin_convertvector(sk, f32x4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-        *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
-    }
-}
-
-// The LAST tap of a layer runs tile-major (8 k-steps of one accumulator tile, then the next
-// tile), so the epilogue of tile t (VALU + LDS) sits between the MFMAs of tile t+1 instead of
-// after all of them: roughly half of the epilogue hides in MFMA issue gaps.
-template <int S, int P>
-__device__ __forceinline__ void last_tap(f32x16 (&acc)[P][2], bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap,
-                                         const char* in, char* out, bool second, const float* __restrict__ bl,
-                                         const int (&boff)[2], int w, int r, int h) {
-    bf16x8 (&use)[8] = S ? A1 : A0;
-    bf16x8 (&nxt)[8] = S ? A0 : A1;
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) nxt[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
-    ap += 8 * 256;
-    f32x4 bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q);
-    bf16x8 bt[2][8];
-#pragma unroll
-    for (int kc = 0; kc < 8; ++kc) bt[0][kc] = *reinterpret_cast<const bf16x8*>(in + (boff[0] ^ (kc << 5)));
-#pragma unroll
-    for (int t = 0; t < 2 * P; ++t) {
-        const int p = t >> 1, nt = t & 1;
-        if (t + 1 < 2 * P) {
-            const int p2 = (t + 1) >> 1, nt2 = (t + 1) & 1;
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc)
-                bt[(t + 1) & 1][kc] = *reinterpret_cast<const bf16x8*>(in + p2 * kTileBytes + (boff[nt2] ^ (kc << 5)));
-        }
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc)
-            acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use[kc], bt[t & 1][kc], acc[p][nt], 0, 0, 0);
-        if (t > 0) epilogue_tile(acc[(t - 1) >> 1][(t - 1) & 1], out, second, bq, (t - 1) >> 1, (t - 1) & 1, w, r, h);
-    }
-    epilogue_tile(acc[P - 1][1], out, second, bq, P - 1, 1, w, r, h);
-}
-
 // One conv3x3 layer over the 4 resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
 // S0 = register set that holds tap 0's weight fragments on entry (the other one on exit).
 template <int S0, int P>
@@ -381,14 +320,9 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
         tap_step<S0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
         tap_step<1 - S0, P>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
     }
-#if BZ_LAST_TAP_TILE_MAJOR
-    BZ_STAMP(t1);
-    last_tap<S0, P>(acc, A0, A1, ap, in, out, second, bl, boff, w, r, h);
-#else
     tap_step<S0, P>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
     BZ_STAMP(t1);
     epilogue<P>(acc, out, second, bl, w, r, h);
-#endif
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);
@@ -404,7 +338,6 @@ struct TowerArgs {
     const uint4* stem_wf;            // [2][4][64] fragments of the stem as a K=32 GEMM (k = 2*tap + plane)
     const float* stem_b;             // [128]
     const uint4* head_wf;            // [8][64] fragments: rows 0,1 = policy conv1x1, row 2 = value conv1x1
-    const uint4 *wf16, *stem_wf16, *head_wf16;  // the same three for the 16x16x32 MFMA shape
     const uint4 *wf8, *head_wf8;     // fp8 (e4m3) fragments for the MX-scaled 32x32x64 MFMA
     const float *dq8, *head_dq8, *ones;  // [n_layers][128] dequant factors 1/(s_w*16), [4], [128] x 1.0f
     const float *pol_b, *val_b;      // [2], [1]
@@ -441,7 +374,7 @@ __device__ __forceinline__ float wave_sum(float x) {
 // the bitboards) -> residual tower (activations resident in LDS) -> heads (conv1x1 by MFMA, the
 // small FCs by one wave per position).  HBM traffic per position: 16 B in, 264 B out.
 template <int P>
-__global__ void __launch_bounds__(256, 4 / P)
+__global__ void __launch_bounds__(256, 1)
 k_tower_bf16(TowerArgs T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -558,242 +491,6 @@ k_tower_bf16(TowerArgs T) {
 #endif
 }
 
-
-// ====================================================================================
-// 16x16x32 variant of the fused net kernel.  Same decomposition (4 positions resident in LDS,
-// wave w owns output channels 32w..32w+31, weights streamed as A operand, one barrier per
-// layer) on v_mfma_f32_16x16x32_bf16: the chip is power-limited on this kernel (1.26 kW at
-// 1.97 GHz with real data, 0.98 kW at 2.39 GHz on zeros) and the 16x16 shape sustains a higher
-// clock per FLOP.  LDS image: per position 4 channel-group planes g = (c%32)/8, each
-// [64 cells x 64 B | 256-B zero region]; the 16-byte chunk of k-step ks sits at slot
-// ks ^ h(cell), h = (x>>2) | (y&1)<<1, so the 16 lanes of a ds_read_b128 group (16 distinct
-// cells of a 2-row tile, any tap shift, halo lanes included) hit 16 distinct bank slots.
-// ====================================================================================
-namespace t16 {
-constexpr int kPlane = 64 * 64 + 256;
-constexpr int kPos = 4 * kPlane;   // 17,408
-constexpr int kBuf = 4 * kPos;     // 69,632
-constexpr int kLds = 2 * kBuf;     // 139,264
-
-__device__ __forceinline__ int cell_addr(int yy, int xx, int g) {  // caller XORs (ks << 4)
-    const bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
-    const int xv = xx & 7;
-    const int h = ((xv >> 2) & 1) | ((yy & 1) << 1);
-    const int base = inb ? (yy * 8 + xx) * 64 : 4096 + (xv & 3) * 64;
-    return g * kPlane + base + (h << 4);
-}
-__device__ __forceinline__ void tap_off(int tap, int c, int g, int (&boff)[4]) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-#pragma unroll
-    for (int bt = 0; bt < 4; ++bt) boff[bt] = cell_addr(2 * bt + (c >> 3) + dy, (c & 7) + dx, g);
-}
-// activation fragments of one half-step: positions 2*half, 2*half+1 x 4 cell tiles
-__device__ __forceinline__ void load_b(bf16x8 (&b)[2][4], const char* in, const int (&boff)[4], int ks, int half) {
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-        for (int bt = 0; bt < 4; ++bt)
-            b[pp][bt] = *reinterpret_cast<const bf16x8*>(in + (2 * half + pp) * kPos + (boff[bt] ^ (ks << 4)));
-}
-__device__ __forceinline__ void mfma16(f32x4 (&acc)[2][4][4], const bf16x8 (&a)[2], const bf16x8 (&b)[2][4], int half) {
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-        for (int bt = 0; bt < 4; ++bt)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[mt][2 * half + pp][bt] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[pp][bt], acc[mt][2 * half + pp][bt], 0, 0, 0);
-}
-
-// one conv tap: 4 k-steps of 32 channels = 8 half-steps of 16 MFMAs; S = register set holding this tap's
-// weight fragments, the other set is filled for the next tap
-template <int S>
-__device__ __forceinline__ void tap_step(f32x4 (&acc)[2][4][4], bf16x8 (&A0)[4][2], bf16x8 (&A1)[4][2], const uint4*& ap,
-                                         const char* in, int (&boff)[4], int next_tap, int c, int g,
-                                         bf16x8 (&b0)[2][4], bf16x8 (&b1)[2][4]) {
-    bf16x8 (&use)[4][2] = S ? A1 : A0;
-    bf16x8 (&nxt)[4][2] = S ? A0 : A1;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) nxt[ks][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(ks * 8 + mt) * 64]);
-    ap += 4 * 8 * 64;
-    int boff_n[4];
-    tap_off(next_tap, c, g, boff_n);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        load_b(b1, in, boff, ks, 1);
-        mfma16(acc, use[ks], b0, 0);
-        if (ks < 3) load_b(b0, in, boff, ks + 1, 0);
-        else load_b(b0, in, boff_n, 0, 0);  // first half-step of the next tap
-        mfma16(acc, use[ks], b1, 1);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
-    }
-#pragma unroll
-    for (int bt = 0; bt < 4; ++bt) boff[bt] = boff_n[bt];
-}
-
-// D[row = co][col = cell]: lane (c, q) register i of tile (mt, p, bt) = channel 32w + 16mt + 4q + i of cell 16bt + c
-__device__ __forceinline__ void epilogue(f32x4 (&acc)[2][4][4], char* out, bool second, const float* __restrict__ bl,
-                                         int w, int c, int q) {
-    f32x4 bq[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) bq[mt] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 16 * mt + 4 * q);
-#pragma unroll
-    for (int bt = 0; bt < 4; ++bt) {
-        const int y = 2 * bt + (c >> 3), x = c & 7;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int base = (cell_addr(y, x, 2 * mt + (q >> 1)) ^ (w << 4)) + 8 * (q & 1);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int off = p * kPos + base;
-                f32x4 v = acc[mt][p][bt] + bq[mt];
-                if (second) {
-                    bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
-                    v = v + __builtin_convertvector(sk, f32x4);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-                *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
-            }
-        }
-    }
-}
-
-template <int S0>
-__device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
-                                           bf16x8 (&A0)[4][2], bf16x8 (&A1)[4][2], const uint4*& ap, int w, int c, int g) {
-    f32x4 acc[2][4][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int bt = 0; bt < 4; ++bt) acc[mt][p][bt] = (f32x4)(0.0f);
-    int boff[4];
-    tap_off(0, c, g, boff);
-    bf16x8 b0[2][4], b1[2][4];
-    load_b(b0, in, boff, 0, 0);
-#pragma unroll 1
-    for (int t = 0; t < 8; t += 2) {
-        tap_step<S0>(acc, A0, A1, ap, in, boff, t + 1, c, g, b0, b1);
-        tap_step<1 - S0>(acc, A0, A1, ap, in, boff, t + 2, c, g, b0, b1);
-    }
-    tap_step<S0>(acc, A0, A1, ap, in, boff, 8, c, g, b0, b1);  // next_tap: harmless re-read
-    epilogue(acc, out, second, bl, w, c, g);
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(256, 1) k_tower16_bf16(TowerArgs T) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos0 = blockIdx.x * 4;
-    if (T.n_dev) T.n = (int)*T.n_dev;
-    if (pos0 >= T.n) return;  // block-uniform, before any barrier
-    char* bufX = smem;
-    char* bufM = smem + kBuf;
-    const int c = lane & 15, g = lane >> 4;  // B/D column (cell in tile), k-group / D row group
-
-    // ---- zero regions (conv halo): 2 buffers x 4 positions x 4 planes x 256 B
-    for (int i = tid; i < 2 * 4 * 4 * 16; i += 256) {
-        int k = i & 15, pl = (i >> 4) & 3, p = (i >> 6) & 3, b = i >> 8;
-        *reinterpret_cast<uint4*>(smem + b * kBuf + p * kPos + pl * kPlane + 4096 + k * 16) = make_uint4(0, 0, 0, 0);
-    }
-    // weight stream of this wave: tap t, k-step ks, 16-row tiles 2w, 2w+1
-    const uint4* ap = T.wf16 + (size_t)(2 * w) * 64 + lane;
-    bf16x8 A0[4][2], A1[4][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) A0[ks][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(ks * 8 + mt) * 64]);
-    ap += 4 * 8 * 64;
-
-    // ---- stem: one K = 32 step (k = 2*tap + plane < 18) straight from the bitboards
-    {
-        f32x4 acc[2][4][4];
-        bf16x8 sa[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) sa[mt] = __builtin_bit_cast(bf16x8, T.stem_wf16[(2 * w + mt) * 64 + lane]);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int pos = pos0 + p < T.n ? pos0 + p : T.n - 1;
-            u64 own = T.own[pos], opp = T.opp[pos];
-#pragma unroll
-            for (int bt = 0; bt < 4; ++bt) {
-                bf16x8 bfr = stem_frag(own, opp, 16 * bt + c, 8 * g);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[mt][p][bt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa[mt], bfr, (f32x4)(0.0f), 0, 0, 0);
-            }
-        }
-        epilogue(acc, bufX, false, T.stem_b, w, c, g);
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int blk = 0; blk < T.n_layers / 2; ++blk) {
-        conv_layer<0>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, c, g);
-        conv_layer<1>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w, c, g);
-    }
-
-    // ---- heads: wave p serves position p
-    if (pos0 + w < T.n) {
-        const int p = w, pos = pos0 + w;
-        float* S = reinterpret_cast<float*>(bufM + p * 1024);  // [pf 128 | vf 64]
-        const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
-#pragma unroll
-        for (int bt = 0; bt < 4; ++bt) {
-            f32x4 acc = (f32x4)(0.0f);
-            const int ca = cell_addr(2 * bt + (c >> 3), c & 7, g);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 a = __builtin_bit_cast(bf16x8, T.head_wf16[ks * 64 + lane]);
-                bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * kPos + (ca ^ (ks << 4)));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-            }
-            if (g == 0) {  // rows 0..2 of D: registers 0..2 of lanes 0..15
-                const int cell = 16 * bt + c;
-                float a0 = acc[0] + pb0, a1 = acc[1] + pb1, a2 = acc[2] + vb;
-                S[cell] = a0 > 0.0f ? a0 : 0.0f;
-                S[64 + cell] = a1 > 0.0f ? a1 : 0.0f;
-                S[128 + cell] = a2 > 0.0f ? a2 : 0.0f;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        float acc = T.polfc_b[lane], part = 0.0f;
-#pragma unroll 4
-        for (int i = 0; i < 128; i += 4) {
-            f32x4 s4 = *reinterpret_cast<const f32x4*>(S + i);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_fmaf(s4[j], T.polfc_wT[(i + j) * 65 + lane], acc);
-        }
-        part = S[lane] * T.polfc_wT[lane * 65 + 64] + S[lane + 64] * T.polfc_wT[(lane + 64) * 65 + 64];
-        part = wave_sum(part);
-        T.logits[(size_t)pos * 65 + lane] = acc;
-        if (lane == 0) T.logits[(size_t)pos * 65 + 64] = part + T.polfc_b[64];
-        float vh = 0.0f;
-        if (lane < T.VH) {
-            float a = T.v1_b[lane];
-#pragma unroll 4
-            for (int i = 0; i < 64; ++i) a = __builtin_fmaf(S[128 + i], T.v1_wT[i * T.VH + lane], a);
-            vh = (a > 0.0f ? a : 0.0f) * T.v2_w[lane];
-        }
-        vh = wave_sum(vh);
-        if (lane == 0) T.value[pos] = tanhf_spec(vh + T.v2_b[0]);
-    }
-}
-}  // namespace t16
 
 // ====================================================================================
 // fp8 variant (BASELINE config 5): same decomposition, tower on
@@ -1085,7 +782,7 @@ struct Carver {
     int64_t take(int64_t bytes) { int64_t o = off; off += (bytes + 255) & ~int64_t(255); return o; }
 };
 struct NetOffsets {
-    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf16, stem_wf16, head_wf16, conv_wf8, head_wf8, dq8, head_dq8, ones, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
+    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf8, head_wf8, dq8, head_dq8, ones, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
         v2_b, act_a, act_b, total;
 };
 NetOffsets net_carve(int C, int NB, int VH, int mb) {
@@ -1096,8 +793,6 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     o.conv_w = k.take(L * 9 * C * C * 4); o.conv_b = k.take(L * C * 4);
     o.conv_wf = k.take(C == kTC ? (L * 9 + 1) * 8LL * 4 * 64 * 16 : 0);
     o.stem_wf = k.take(2 * 4 * 64 * 16); o.head_wf = k.take(8 * 64 * 16);
-    o.conv_wf16 = k.take(C == kTC ? (L * 9 + 1) * 4LL * 8 * 64 * 16 : 0);
-    o.stem_wf16 = k.take(8 * 64 * 16); o.head_wf16 = k.take(4 * 64 * 16);
     o.conv_wf8 = k.take(C == kTC ? (L * 9 + 1) * 2LL * 4 * 2 * 64 * 16 : 0); o.head_wf8 = k.take(2 * 2 * 64 * 16);
     o.dq8 = k.take((L + 1) * 128 * 4); o.head_dq8 = k.take(16); o.ones = k.take(128 * 4);
     o.pol_w = k.take(2LL * C * 4); o.pol_b = k.take(8); o.polfc_wT = k.take(128 * 65 * 4); o.polfc_b = k.take(65 * 4);
@@ -1169,21 +864,10 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                         sf[(((size_t)kc * 4 + mt) * 64 + ln) * 8 + j] = f2bf(v);
                     }
     }
-    if (C == kTC) {  // 16x16x32 shape: A[row = co%16][k = 8g + j], one K = 32 step
-        uint16_t* sf = reinterpret_cast<uint16_t*>(img.data() + o.stem_wf16);
-        for (int tile = 0; tile < 8; ++tile)
-            for (int ln = 0; ln < 64; ++ln)
-                for (int j = 0; j < 8; ++j) {
-                    int co = 16 * tile + (ln & 15), k = 8 * (ln >> 4) + j;
-                    float v = k < 18 ? q[(co * 2 + (k & 1)) * 9 + (k >> 1)] : 0.0f;
-                    sf[((size_t)tile * 64 + ln) * 8 + j] = f2bf(v);
-                }
-    }
     q += (size_t)C * 18;
     for (int i = 0; i < C; ++i) F(o.stem_b)[i] = q[i];
     q += C;
     uint16_t* wf = reinterpret_cast<uint16_t*>(img.data() + o.conv_wf);
-    uint16_t* wf16 = reinterpret_cast<uint16_t*>(img.data() + o.conv_wf16);
     for (int l = 0; l < L; ++l) {
         float* wl = F(o.conv_w) + (size_t)l * 9 * C * C;
         for (int co = 0; co < C; ++co)
@@ -1195,10 +879,6 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                         int kc = ci >> 4, hh = (ci >> 3) & 1, j = ci & 7, mt = co >> 5, rr = co & 31;
                         size_t f = ((((size_t)l * 9 + t) * 8 + kc) * 4 + mt) * 64 + (hh * 32 + rr);
                         wf[f * 8 + j] = f2bf(v);
-                        // 16x16x32 shape: [l][t][ks][tile16][lane = 16g + row][j]
-                        int ks = ci >> 5, g16 = (ci >> 3) & 3, tile = co >> 4, row = co & 15;
-                        size_t f16 = ((((size_t)l * 9 + t) * 4 + ks) * 8 + tile) * 64 + (g16 * 16 + row);
-                        wf16[f16 * 8 + j] = f2bf(v);
                     }
                 }
         q += (size_t)C * C * 9;
@@ -1268,14 +948,6 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                     float v = row < 2 ? F(o.pol_w)[row * C + k] * hs[row] : (row == 2 ? F(o.val_w)[k] * hs[2] : 0.0f);
                     h8[((size_t)(ks * 2 + (j >> 4)) * 64 + ln) * 16 + (j & 15)] = f2e4m3(v);
                 }
-        uint16_t* hf16 = reinterpret_cast<uint16_t*>(img.data() + o.head_wf16);
-        for (int ks = 0; ks < 4; ++ks)
-            for (int ln = 0; ln < 64; ++ln)
-                for (int j = 0; j < 8; ++j) {
-                    int row = ln & 15, k = 32 * ks + 8 * (ln >> 4) + j;
-                    float v = row < 2 ? F(o.pol_w)[row * C + k] : (row == 2 ? F(o.val_w)[k] : 0.0f);
-                    hf16[((size_t)ks * 64 + ln) * 8 + j] = f2bf(v);
-                }
     }
     hipError_t e1 = hipMemcpyAsync(ws, img.data(), (size_t)param_bytes, hipMemcpyHostToDevice, s);
     hipError_t e2 = e1 == hipSuccess ? hipStreamSynchronize(s) : e1;
@@ -1310,8 +982,6 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->conv_w = at<float>(ws, o.conv_w); n->conv_b = at<float>(ws, o.conv_b);
     n->conv_wf = C == kTC ? at<__bf16>(ws, o.conv_wf) : nullptr;
     n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
-    n->conv_wf16 = C == kTC ? at<__bf16>(ws, o.conv_wf16) : nullptr;
-    n->stem_wf16 = at<__bf16>(ws, o.stem_wf16); n->head_wf16 = at<__bf16>(ws, o.head_wf16);
     n->conv_wf8 = C == kTC ? at<uint8_t>(ws, o.conv_wf8) : nullptr; n->head_wf8 = at<uint8_t>(ws, o.head_wf8);
     n->dq8 = at<float>(ws, o.dq8); n->head_dq8 = at<float>(ws, o.head_dq8); n->ones = at<float>(ws, o.ones);
     n->pol_w = at<float>(ws, o.pol_w); n->pol_b = at<float>(ws, o.pol_b);
@@ -1322,15 +992,16 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->act_a = at<float>(ws, o.act_a); n->act_b = at<float>(ws, o.act_b);
 
     n->ws_base = ws;
+    n->f32_used = false;
+    if (hipEventCreateWithFlags(&n->f32_done, hipEventDisableTiming) != hipSuccess) {
+        delete n; set_error("bz_net_create: hipEventCreate failed"); return BZ_EHIP;
+    }
     int32_t urc = upload_params(n, p, (hipStream_t)stream);
     if (urc != BZ_OK) { delete n; return urc; }
     if (C == kTC) {
         hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<kPosPerWG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
-        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(t16::k_tower16_bf16),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, t16::kLds);
-        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower16_bf16)"); }
         e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(f8::k_tower_fp8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  f8::kLds);
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_fp8)"); }
@@ -1339,10 +1010,16 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_net_destroy(bz_net* net) { delete net; return BZ_OK; }
+BZ_EXPORT int32_t bz_net_destroy(bz_net* net) {
+    if (net) (void)hipEventDestroy(net->f32_done);
+    delete net;
+    return BZ_OK;
+}
 
 BZ_EXPORT int32_t bz_net_update(bz_net* net, const float* params_host, void* stream) {
     BZ_REQUIRE(net && params_host, "bz_net_update: null pointer");
+    // searches in flight on ANY stream must not see half-replaced weights: drain the device first
+    BZ_HIP(hipDeviceSynchronize());
     return upload_params(net, params_host, (hipStream_t)stream);
 }
 
@@ -1358,6 +1035,7 @@ static int32_t forward_f32(bz_net* n, const uint64_t* own, const uint64_t* opp, 
                            float* logits, float* value, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int C = n->C;
+    if (n->f32_used) BZ_HIP(hipStreamWaitEvent(s, n->f32_done, 0));
     hipLaunchKernelGGL(k_stem<float>, dim3(cnt), dim3(C), 0, s, own, opp, cnt, n_dev, C, n->stem_w, n->stem_b, n->act_a);
     BZ_LAUNCH_CHECK("k_stem<float>");
     size_t lds = (size_t)64 * C * sizeof(float);
@@ -1375,6 +1053,8 @@ static int32_t forward_f32(bz_net* n, const uint64_t* own, const uint64_t* opp, 
     hipLaunchKernelGGL(k_heads<float>, dim3(cnt), dim3(192), hl, s, n->act_a, cnt, n_dev, n->C, n->VH, n->pol_w, n->pol_b,
                        n->polfc_wT, n->polfc_b, n->val_w, n->val_b, n->v1_wT, n->v1_b, n->v2_w, n->v2_b, logits, value);
     BZ_LAUNCH_CHECK("k_heads<float>");
+    BZ_HIP(hipEventRecord(n->f32_done, s));
+    n->f32_used = true;
     return BZ_OK;
 }
 
@@ -1386,8 +1066,6 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     T.wf = reinterpret_cast<const uint4*>(n->conv_wf); T.bias = n->conv_b;
     T.stem_wf = reinterpret_cast<const uint4*>(n->stem_wf); T.stem_b = n->stem_b;
     T.head_wf = reinterpret_cast<const uint4*>(n->head_wf); T.pol_b = n->pol_b; T.val_b = n->val_b;
-    T.wf16 = reinterpret_cast<const uint4*>(n->conv_wf16); T.stem_wf16 = reinterpret_cast<const uint4*>(n->stem_wf16);
-    T.head_wf16 = reinterpret_cast<const uint4*>(n->head_wf16);
     T.wf8 = reinterpret_cast<const uint4*>(n->conv_wf8); T.head_wf8 = reinterpret_cast<const uint4*>(n->head_wf8);
     T.dq8 = n->dq8; T.head_dq8 = n->head_dq8; T.ones = n->ones;
     T.polfc_wT = n->polfc_wT; T.polfc_b = n->polfc_b; T.v1_wT = n->v1_wT; T.v1_b = n->v1_b; T.v2_w = n->v2_w;
@@ -1396,12 +1074,8 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
         ProfScope ps(BZ_PROF_TOWER, stream);
         if (fp8) hipLaunchKernelGGL(f8::k_tower_fp8, dim3((cnt + 3) / 4), dim3(256), f8::kLds, s, T);
         else
-#if BZ_TOWER_SHAPE == 16
-        hipLaunchKernelGGL(t16::k_tower16_bf16, dim3((cnt + 3) / 4), dim3(256), t16::kLds, s, T);
-#else
-        hipLaunchKernelGGL(k_tower_bf16<kPosPerWG>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
-                           tower_lds<kPosPerWG>(), s, T);
-#endif
+            hipLaunchKernelGGL(k_tower_bf16<kPosPerWG>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
+                               tower_lds<kPosPerWG>(), s, T);
     }
     BZ_LAUNCH_CHECK("k_tower_bf16");
     return BZ_OK;

@@ -1,48 +1,48 @@
-"""Pool (s, pi, z) examples across the GPUs of a node: one all-gather of the
-fixed-capacity example buffers at iteration end (RCCL over xGMI when the
-process group backend is "nccl"; gloo on CPU for tests).  Games shard
-embarrassingly, so this is the only collective on the path."""
-import numpy as np
+"""Pool (s, pi, z) examples across the GPUs of a node: ONE all-gather of the fixed-capacity
+example blocks at iteration end (RCCL over xGMI when the process group backend is "nccl"; gloo on
+CPU for tests).  Games shard embarrassingly, so this is the only collective on the path
+(SURVEY.md 8(e)).
+
+What travels is each engine's example block: the contiguous byte range [ex_own .. ex_winner |
+256-byte header] of its workspace (SelfPlayEngine.example_block(), include/bz_abi.h).  The header
+carries the rank's game-id base / stride and the array geometry, and `ex_len` carries the valid
+row counts, so neither a second collective for metadata nor an all-gather-v is needed."""
 import torch
 import torch.distributed as dist
 
-from .engine import pack_examples
-
-_KEYS = ("own", "opp", "pi", "z", "mover", "act", "len", "winner")
+from .engine import concat_examples, unpack_example_block
 
 
-def all_gather_example_tensors(tensors, group=None):
-    """tensors: dict of [R,B,T,...] tensors (SelfPlayEngine.example_tensors()).
-    Returns dict of [world, R, B, T, ...] tensors on the same device.  Every rank
-    contributes the same fixed capacity, so no all-gather-v is needed; the `len`
-    array carries the valid row counts."""
+def all_gather_example_blocks(blocks, group=None):
+    """blocks: the example blocks (1-D uint8 tensors) of this rank's engines -- one, or one per
+    pipeline.  Issues exactly ONE collective and returns (gathered [world, bytes] uint8 tensor,
+    per-engine block sizes).  A single block is sent in place (no copy); several are first laid
+    side by side in one send buffer (a device-to-device copy)."""
+    sizes = [int(b.numel()) for b in blocks]
+    send = blocks[0] if len(blocks) == 1 else torch.cat([b.reshape(-1) for b in blocks])
     world = dist.get_world_size(group)
-    out = {}
-    for k in _KEYS:
-        t = tensors[k].contiguous()
-        flat = t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1)
-        buf = torch.empty((world,) + tuple(flat.shape), dtype=torch.uint8, device=flat.device)
-        dist.all_gather_into_tensor(buf.view(-1), flat, group=group) if flat.is_cuda else \
-            dist.all_gather(list(buf.unbind(0)), flat, group=group)
-        out[k] = buf.view(world, -1).view(t.dtype).view((world,) + tuple(t.shape))
-    return out
+    out = torch.empty((world, send.numel()), dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(out.view(-1), send.contiguous(), group=group)
+    return out, sizes
 
 
-def gather_examples(engine, group=None):
-    """All ranks get the pooled Examples of every rank's finished games (global game ids come from each
-    rank's own game_id_base / game_id_stride, gathered alongside the buffers)."""
-    g = all_gather_example_tensors(engine.example_tensors(), group)
-    world = dist.get_world_size(group)
-    dev = next(iter(g.values())).device
-    meta = torch.tensor([int(engine.cfg.game_id_base), int(engine.cfg.game_id_stride)], dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    parts = []
-    size = getattr(engine, "size", 3 if engine.t_max == 9 else 8)
-    for r in range(world):
-        t = {k: g[k][r].cpu().numpy() for k in _KEYS}
-        base, stride = (int(v) for v in metas[r].cpu())
-        parts.append(pack_examples(t, base, stride, size))
-    from .engine import Examples
-    cat = lambda f: np.concatenate([getattr(p, f) for p in parts])  # noqa: E731
-    return Examples(cat("own"), cat("opp"), cat("pi"), cat("z"), cat("mover"), cat("act"), cat("game"), cat("ply"), size)
+def split_gathered(gathered, sizes):
+    """[world, bytes] -> list over ranks of lists over engines of block views"""
+    res = []
+    for r in range(gathered.shape[0]):
+        off, row = 0, []
+        for n in sizes:
+            row.append(gathered[r, off:off + n])
+            off += n
+        res.append(row)
+    return res
+
+
+def gather_examples(engines, group=None):
+    """All ranks get the pooled Examples of every rank's finished games.  `engines`: one
+    SelfPlayEngine or a list of them (the pipelines of this rank).  One collective; the finished
+    rows are selected where the gathered buffer lives, so only they are copied to the host."""
+    if not isinstance(engines, (list, tuple)):
+        engines = [engines]
+    gathered, sizes = all_gather_example_blocks([e.example_block() for e in engines], group)
+    return concat_examples([unpack_example_block(b) for row in split_gathered(gathered, sizes) for b in row])

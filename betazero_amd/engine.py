@@ -172,10 +172,15 @@ class SelfPlayEngine:
                 "len": self._view(self.lay.ex_len, torch.int32, (R, B)),
                 "winner": self._view(self.lay.ex_winner, torch.int8, (R, B))}
 
+    def example_block(self):
+        """the ONE contiguous, self-describing byte range [ex_own .. ex_winner | 256-B header] of the
+        workspace (uint8 view, no copy) -- what the iteration-end all-gather ships"""
+        o = self._pad + self.lay.ex_begin
+        return self.ws[o:o + self.lay.ex_bytes]
+
     def examples(self):
-        return pack_examples({k: v.cpu().numpy() for k, v in self.example_tensors().items()},
-                             int(self.cfg.game_id_base), int(self.cfg.game_id_stride),
-                             _SIZES[self.game])
+        """finished games' rows, compacted on the device; only the valid rows cross PCIe"""
+        return unpack_example_block(self.example_block())
 
     def winners(self):
         t = self.example_tensors()
@@ -199,6 +204,70 @@ class SelfPlayEngine:
             _lib.lib().bz_engine_destroy(self.h)
         except Exception:
             pass
+
+
+EX_MAGIC = 0x425A455841000002
+_EX_FIELDS = (("own", torch.int64, 8), ("opp", torch.int64, 8), ("pi", torch.float32, 4), ("z", torch.int8, 1),
+              ("mover", torch.int8, 1), ("act", torch.uint8, 1), ("len", torch.int32, 4), ("winner", torch.int8, 1))
+
+
+def example_block_views(block):
+    """uint8 example block (device or host tensor) -> (dict of [R,B,T,...] tensor views, meta dict).
+    The block describes itself through its trailing 256-byte header (include/bz_abi.h)."""
+    meta = block[-256:].cpu().numpy().view(np.uint64)
+    if int(meta[0]) != EX_MAGIC:
+        raise ValueError("not a betazero_amd example block (bad magic)")
+    base, stride, B, R, T, na, game = (int(v) for v in meta[1:8])
+    offs = [int(v) for v in meta[8:16]]
+    shapes = {"own": (R, B, T), "opp": (R, B, T), "pi": (R, B, T, na), "z": (R, B, T), "mover": (R, B, T),
+              "act": (R, B, T), "len": (R, B), "winner": (R, B)}
+    out = {}
+    for (name, dt, esz), off in zip(_EX_FIELDS, offs):
+        n = int(np.prod(shapes[name])) * esz
+        out[name] = block[off:off + n].view(dt).view(*shapes[name])
+    return out, {"game_id_base": base, "game_id_stride": stride, "B": B, "rounds": R, "t_max": T, "na": na,
+                 "game": game, "size": _SIZES[game]}
+
+
+def build_example_block(arrays, game_id_base, game_id_stride, game, device="cpu"):
+    """host-side constructor of an example block with the engine's exact layout (256-byte aligned
+    arrays + header): `arrays` = dict of [R,B,T,...] tensors as example_tensors() returns them.
+    Used to re-load saved examples and by the CPU rehearsal of the multi-GPU path."""
+    R, B, T = arrays["own"].shape
+    na = arrays["pi"].shape[-1]
+    offs, off = [], 0
+    for name, dt, esz in _EX_FIELDS:
+        offs.append(off)
+        off += (arrays[name].numel() * esz + 255) & ~255
+    block = torch.zeros(off + 256, dtype=torch.uint8, device=device)
+    for (name, dt, esz), o in zip(_EX_FIELDS, offs):
+        a = arrays[name].to(device=device, dtype=dt).contiguous()
+        block[o:o + a.numel() * esz] = a.view(torch.uint8).reshape(-1)
+    meta = np.zeros(32, np.uint64)
+    meta[0:8] = [EX_MAGIC, game_id_base, game_id_stride, B, R, T, na, _GAMES[game]]
+    meta[8:16] = offs
+    block[off:off + 256] = torch.from_numpy(meta.view(np.uint8).copy()).to(device)
+    return block
+
+
+def unpack_example_block(block):
+    """example block -> compact Examples of the finished games; the row selection runs where the
+    block lives (on the GPU for a device block), so only valid rows are copied to the host"""
+    t, m = example_block_views(block)
+    T = m["t_max"]
+    valid = torch.arange(T, device=block.device)[None, None, :] < t["len"][:, :, None]
+    r, b, k = valid.nonzero(as_tuple=True)
+    pick = lambda a: a[r, b, k].cpu().numpy()  # noqa: E731
+    gid = m["game_id_base"] + r.cpu().numpy().astype(np.int64) * m["game_id_stride"] + b.cpu().numpy()
+    return Examples(own=pick(t["own"]).view(np.uint64), opp=pick(t["opp"]).view(np.uint64), pi=pick(t["pi"]),
+                    z=pick(t["z"]), mover=pick(t["mover"]), act=pick(t["act"]), game=gid,
+                    ply=k.cpu().numpy().astype(np.int32), size=m["size"])
+
+
+def concat_examples(parts):
+    cat = lambda f: np.concatenate([getattr(p, f) for p in parts])  # noqa: E731
+    return Examples(cat("own"), cat("opp"), cat("pi"), cat("z"), cat("mover"), cat("act"), cat("game"), cat("ply"),
+                    parts[0].size)
 
 
 def pack_examples(t, id_base, id_stride, size):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 1
+#define BZ_ABI_VERSION 2
 
 enum { BZ_OK = 0, BZ_EINVAL = 1, BZ_EILLEGAL_MOVE = 2, BZ_EHIP = 3, BZ_ENOMEM = 4, BZ_ENOGPU = 5,
        BZ_ESTATE = 6 };
@@ -48,6 +48,9 @@ enum { BZ_EVAL_UNIFORM = 0, BZ_EVAL_HASH = 1, BZ_EVAL_NET_F32 = 2, BZ_EVAL_NET_B
 
 int32_t bz_abi_version(void);
 const char* bz_last_error(void);
+/* the -D flags this library was compiled with ("product" for the shipped build; diagnostic
+ * variants carry BZ_EXPERIMENT and are refused by the Python binding unless asked for) */
+const char* bz_build_info(void);
 /* number of visible HIP devices (0 on a CPU-only host); never fails */
 int32_t bz_device_count(void);
 
@@ -100,6 +103,10 @@ int32_t bz_reversi_step_batch_sized(const uint64_t* own, const uint64_t* opp, co
                                     uint8_t* status, int8_t* winner, void* stream);
 int32_t bz_reversi_legal_batch(const uint64_t* own, const uint64_t* opp, int64_t n, uint64_t* legal,
                                void* stream);
+/* ReversiBoard.get_score  reversi_board.py:67-85 for n boards: x = +1 stones, o = -1 stones;
+ * winner[n] = +1/-1/0, counts[n][2] = (n_x, n_o) */
+int32_t bz_reversi_score_batch(const uint64_t* x, const uint64_t* o, int64_t n, int8_t* winner,
+                               uint8_t* counts, void* stream);
 /* Tic-tac-toe: to_move[n] = absolute colour (+1/-1) of the mover; winner is the
  * ABSOLUTE colour (+1/-1/0) exactly as TicTacToeBoard.is_game_over returns it. */
 int32_t bz_ttt_step_batch(const uint16_t* own, const uint16_t* opp, const uint8_t* action,
@@ -189,6 +196,11 @@ typedef struct bz_engine_layout {
     int64_t g_to_move, g_state;     /* i8 / u8 [B]  (state: 0 active, 1 finished)     */
     int64_t counters;               /* u64 [16] work counters           */
     int32_t na, t_max;
+    /* The example arrays ex_own .. ex_winner are consecutive in the workspace and are followed by
+     * a 256-byte header (ex_meta: u64 magic, game_id_base, game_id_stride, B, rounds, t_max, NA,
+     * game, then the 8 array offsets relative to ex_begin).  [ex_begin, ex_begin + ex_bytes) is the
+     * ONE contiguous, self-describing byte range that the iteration-end all-gather ships. */
+    int64_t ex_begin, ex_bytes, ex_meta;
 } bz_engine_layout;
 
 int64_t bz_engine_workspace_bytes(const bz_engine_cfg* cfg);
@@ -234,6 +246,9 @@ int32_t bz_engine_sum_counters(bz_engine* e, void* stream);
 enum { BZ_PROF_TOWER = 0, BZ_PROF_STEM = 1, BZ_PROF_HEADS = 2, BZ_PROF_SELECT = 3, BZ_PROF_EXPAND_BACKUP = 4,
        BZ_PROF_SEARCH_FUSED = 5, BZ_PROF_PLAY = 6, BZ_PROF_ENV_STEP = 7, BZ_PROF_N = 8 };
 int32_t bz_profile_enable(int32_t on);
+/* create the events for n_launches launches of a slot up front (keeps event creation out of a
+ * timed loop); a slot records at most 262,144 launches between two resets */
+int32_t bz_profile_reserve(int32_t slot, int64_t n_launches);
 /* synchronises the device; launches = all launches seen, timed = launches that
  * carried events (capped), total_ms = sum of their durations */
 int32_t bz_profile_read(int32_t slot, int64_t* launches, int64_t* timed, double* total_ms);

@@ -24,12 +24,12 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(L, n), f"{n} declared in bz_abi.h but not exported"
     assert set(names) == set(_lib.ABI_SYMBOLS)
-    assert L.bz_abi_version() == 1
+    assert L.bz_abi_version() == _lib.ABI_VERSION and L.bz_build_info() == b"product"
 
 
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.EngineCfg) == 64
-    assert C.sizeof(_lib.EngineLayout) == 21 * 8 + 8
+    assert C.sizeof(_lib.EngineLayout) == 21 * 8 + 8 + 3 * 8
 
 
 def test_argument_validation_without_gpu():

@@ -1,12 +1,18 @@
-"""N>1 path on CPU: world_size-2 gloo all-gather of rank-tagged example buffers
-(the one collective on the path; on GPUs the same code runs over RCCL)."""
+"""N>1 path on CPU: world_size-2 gloo rehearsals of the one collective on the path -- the all-gather
+of the engines' self-describing example blocks (on GPUs the same code runs over RCCL) -- and of
+`python bench.py --gpus 2`, which has to start its two ranks by itself."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -17,9 +23,9 @@ def _free_port():
     return p
 
 
-def _fake_buffers(rank, R, B, T, na):
-    """deterministic per-rank payload: every row tagged with (rank, round, slot, t)"""
-    g = torch.Generator().manual_seed(100 + rank)
+def _fake_buffers(rank, eng, R, B, T, na):
+    """deterministic per-(rank, engine) payload"""
+    g = torch.Generator().manual_seed(100 + 10 * rank + eng)
     own = torch.randint(0, 2**62, (R, B, T), generator=g, dtype=torch.int64)
     ln = torch.randint(0, T + 1, (R, B), generator=g, dtype=torch.int32)
     ln[0, 0] = -1  # an unfinished game contributes nothing
@@ -30,43 +36,52 @@ def _fake_buffers(rank, R, B, T, na):
             "winner": torch.randint(-1, 2, (R, B), generator=g, dtype=torch.int8)}
 
 
+class _FakeEngine:
+    def __init__(self, block):
+        self._b = block
+
+    def example_block(self):
+        return self._b
+
+
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from betazero_amd.distributed import all_gather_example_tensors
-    from betazero_amd.engine import pack_examples
-    R, B, T, na = 2, 5, 9, 9
-    mine = _fake_buffers(rank, R, B, T, na)
-    g = all_gather_example_tensors(mine)
-    ok = True
+    from betazero_amd import distributed as bd
+    from betazero_amd.engine import build_example_block, example_block_views, unpack_example_block
+    R, B, T, na, NE = 2, 5, 9, 9, 2  # NE engines (pipelines) per rank, as in bench.py
+    base = lambda r, e: 1000 * r + 100 * e + 7  # noqa: E731
+    blocks = [build_example_block(_fake_buffers(rank, e, R, B, T, na), base(rank, e), 50, "ttt") for e in range(NE)]
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    gathered, sizes = bd.all_gather_example_blocks(blocks)
+    ok = len(calls) == 1 and gathered.shape == (world, sum(sizes))  # ONE collective for both engines
     total = 0
+    parts = bd.split_gathered(gathered, sizes)
     for r in range(world):
-        exp = _fake_buffers(r, R, B, T, na)
-        for k in exp:
-            ok &= bool(torch.equal(g[k][r], exp[k]))
-        ex = pack_examples({k: v[r].numpy() for k, v in g.items()}, r * B, world * B, 3)
-        n_rows = int(exp["len"].clamp(min=0).sum())
-        ok &= len(ex) == n_rows
-        ok &= bool(np.all((ex.game - r * B) % (world * B) < B))  # ids stay in the rank's shard
-        total += n_rows
-    # gather_examples() with an engine stand-in: ids come from each rank's own base/stride
-    from types import SimpleNamespace
-    from betazero_amd.distributed import gather_examples
-    fake = SimpleNamespace(example_tensors=lambda: mine, cfg=SimpleNamespace(game_id_base=1000 * rank + 7, game_id_stride=50),
-                           t_max=9, B=B)
-    pooled = gather_examples(fake)
-    ok &= len(pooled) == total
-    ids = set((pooled.game % 1000 if False else pooled.game).tolist())
-    for r in range(world):
-        exp = _fake_buffers(r, R, B, T, na)
-        valid = exp["len"].numpy() > 0
-        want = {1000 * r + 7 + rr * 50 + b for rr in range(R) for b in range(B) if valid[rr, b]}
-        ok &= want <= ids
-    out.put((rank, ok, total))
+        for e in range(NE):
+            exp = _fake_buffers(r, e, R, B, T, na)
+            views, meta = example_block_views(parts[r][e])
+            for k in exp:
+                ok &= bool(torch.equal(views[k], exp[k]))
+            ok &= (meta["game_id_base"], meta["game_id_stride"], meta["B"], meta["rounds"]) == (base(r, e), 50, B, R)
+            ex = unpack_example_block(parts[r][e])
+            n_rows = int(exp["len"].clamp(min=0).sum())
+            ok &= len(ex) == n_rows and ex.size == 3
+            valid = exp["len"].numpy() > 0
+            want = {base(r, e) + rr * 50 + b for rr in range(R) for b in range(B) if valid[rr, b]}
+            ok &= set(ex.game.tolist()) == want  # ids come from each block's own header
+            total += n_rows
+    calls.clear()
+    pooled = bd.gather_examples([_FakeEngine(b) for b in blocks])
+    ok &= len(calls) == 1 and len(pooled) == total
+    dist.all_gather_into_tensor = real
+    out.put((rank, bool(ok), total))
     dist.destroy_process_group()
 
 
-def test_all_gather_examples_world2_gloo():
+def test_all_gather_example_blocks_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -76,3 +91,27 @@ def test_all_gather_examples_world2_gloo():
     [p.join(timeout=60) for p in ps]
     assert all(ok for _, ok, _ in res)
     assert res[0][2] == res[1][2] > 0  # every rank sees the same pooled row count
+
+
+def test_bench_gpus2_starts_its_own_ranks_cpu_rehearsal():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start two ranks itself.  Without a
+    GPU the ranks run the rehearsal leg (BZ_BENCH_REHEARSAL=1: process group, the single all-gather on
+    blocks of the cfg-3 geometry scaled down, barrier + max-over-ranks timing) and rank 0 prints the line."""
+    env = dict(os.environ, BZ_BENCH_REHEARSAL="1", BZ_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--games", "64"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["collectives"] == 1
+    assert out["gathered_bytes"] == 2 * out["block_bytes_per_rank"] and out["pooled_rows"] > 0
+
+
+def test_bench_refuses_gpu_count_mismatch():
+    env = dict(os.environ, BZ_BENCH_REHEARSAL="1", WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus" in (r.stderr + r.stdout)
