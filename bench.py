@@ -51,8 +51,32 @@ def tree_bytes(c):
             13 * c["n_child_written"] + 264 * c["n_net_leaves"] + 42 * c["n_env_steps"])
 
 
+_T0 = time.time()
+
+
+def note(msg):
+    """progress line on stderr (stdout carries only the JSON line)"""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def host_cores():
-    return max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    """cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota (a
+    container on a 256-thread host may be given 16: one thread per USABLE core, not per visible one)"""
+    n = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p_))
+        except Exception:
+            pass
+    return n
 
 
 # ------------------------------------------------------------------ N ranks from one command
@@ -117,6 +141,33 @@ def rehearsal(args, rank, world):
                           "gathered_bytes": int(gathered.numel()), "pooled_rows": int(rows)}))
 
 
+def usable_cores():
+    """host_cores() verified by a 1-vs-n thread probe of the oracle (a CPU quota this process cannot
+    read would otherwise oversubscribe the baseline run many times over): threads beyond what the
+    probe shows to run in parallel are not used"""
+    import numpy as np
+    from oracle import oracle as orc
+    n = host_cores()
+    if n == 1:
+        return 1
+    rng = np.random.default_rng(0)
+    net = orc.Net(64, 2, 64, rng.standard_normal(orc.lib().orc_net_param_count(64, 2, 64)).astype(np.float32) * 0.05)
+    own = np.array([0x0000000810000000] * 16, np.uint64)
+    opp = np.array([0x0000001008000000] * 16, np.uint64)
+
+    def spin(k):
+        for _ in range(k):
+            net.forward(own, opp)  # a few tens of ms inside the C library (GIL released)
+    spin(1)
+    t0 = time.time(); spin(4); t1 = time.time() - t0
+    tn = None
+    for _ in range(2):  # best of two: a noisy neighbour must not halve the estimate
+        th = [threading.Thread(target=spin, args=(4,)) for _ in range(n)]
+        t0 = time.time(); [t.start() for t in th]; [t.join() for t in th]
+        tn = min(tn or 1e9, time.time() - t0)
+    return max(1, min(n, int(n * t1 / tn + 0.5)))
+
+
 # ------------------------------------------------------------------ CPU baselines (rank 0, N = 1)
 def cpu_baseline_reversi(sims, budget_s=12.0):
     """(i) "port": the C oracle on ALL host cores, one game per thread, 2 searched moves each of cfg-3
@@ -132,7 +183,7 @@ def cpu_baseline_reversi(sims, budget_s=12.0):
     torch.manual_seed(0)
     mod = PolicyValueNet(128, 6, 64).round_to_bf16_()
     net = orc.Net(128, 6, 64, mod.flat_params())
-    cores = host_cores()
+    cores = usable_cores()
     moves = 2
     done = [0] * cores
 
@@ -183,7 +234,7 @@ def cpu_baseline_reversi(sims, budget_s=12.0):
 
 def cpu_baseline_ttt(sims):
     from oracle import oracle as orc
-    cores = host_cores()
+    cores = usable_cores()
     per = 4000
     t0 = time.time()
 
@@ -342,9 +393,11 @@ def run_reversi(ctx, args, B, sims, K, W):
             ctx.sync()
             active = any(e.status()[0] > 0 for e in engs)
 
+    note(f"reversi: engines up ({NS} x {Bs} games, {sims} sims), warm-up {W} steps")
     for _ in range(W):
         step()
     ctx.sync()
+    note("warm-up done")
     fin0 = sum(e.status()[1] for e in engs)
     for e in engs:
         e.reset_counters()
@@ -356,6 +409,7 @@ def run_reversi(ctx, args, B, sims, K, W):
             L.bz_profile_reserve(_lib.PROF_SLOTS.index(slot), per)
     L.bz_profile_enable(1 if prof_on else 0)
     ctx.barrier()
+    note(f"timed region: {K} steps")
     t0 = time.perf_counter()
     for _ in range(K):
         step()
@@ -371,6 +425,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     ctx.barrier()
     dt = time.perf_counter() - t0
     L.bz_profile_enable(0)
+    note(f"timed region done: {dt:.2f} s")
     fin1 = sum(e.status()[1] for e in engs)  # status() raises on engine error flags
     if args.mode == "iteration":
         fin1, fin0 = K * B, 0
@@ -401,6 +456,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     kname = ("k_tower_bf16" if prec == "bf16" else "f8::k_tower_fp8") + " (stem + 12 conv3x3 + heads, fused)"
     if prof_on:
         prof = _lib.profile_read()
+        note("kernel timers read")
         launches, timed, ms = prof["tower"]
         assert timed == launches, f"kernel-timer capacity exceeded ({timed} of {launches} launches timed)"
         # leaves are packed before the net runs: a launch evaluates only the non-terminal leaves
@@ -533,6 +589,7 @@ def main():
                 for name, fn in (("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
                                  ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True))):
                     try:
+                        note(f"secondary {name}")
                         r = fn()
                         sec[name] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config",
                                                        "roofline")}
@@ -540,7 +597,9 @@ def main():
                         sec[name] = {"error": repr(e)}
                 out["secondary"] = sec
             if not args.no_cpu_baseline:
+                note("cpu baseline (oracle port on all cores, then the Python loop on one)")
                 out["cpu_baseline"] = cpu_baseline_reversi(sims)
+                note("cpu baseline done")
     if ctx.rank == 0:
         out["n_gpus"] = dist.get_world_size() if ctx.world > 1 else 1
         assert out["n_gpus"] == args.gpus

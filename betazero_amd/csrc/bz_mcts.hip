@@ -87,9 +87,24 @@ __global__ void __launch_bounds__(256) k_sum_counters(EngineDev E) {
 
 // Orders a lane group's earlier stores (edges / node header written by dev_expand, child node
 // written by dev_select) before its later loads of the same addresses.  All communication is
-// between lanes of ONE wave (a game's G::GW lanes), which share the CU's L1, so workgroup scope
-// is enough; acq_rel so that neither the stores nor the following loads may move across it.
-__device__ __forceinline__ void group_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+// between lanes of ONE wave (a game's G::GW lanes divide 64), so WAVEFRONT scope is the exact
+// scope: acq_rel keeps the compiler from moving the stores or the following loads across it,
+// and the hardware executes one wave's vector-memory instructions to an address in issue order,
+// so no s_waitcnt vmcnt(0) (a full store round trip, which a workgroup-scope fence costs) is needed.
+__device__ __forceinline__ void group_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// where the select walk records its path (edge index + that edge's N and W at selection time, so
+// that the backup is a pure store): HBM, depth-major across games, for the step-by-step kernels
+// whose backup runs in a later launch; LDS for the fused search.
+struct PathEnt { u32 eidx; u32 N; float W; };
+struct PathHbm {
+    const EngineDev& E; int g;
+    __device__ __forceinline__ void put(int d, u32 eidx, u32, float) const { E.path[(size_t)d * E.B + g] = eidx; }
+};
+struct PathLds {
+    PathEnt* p;  // this game's MAXD entries
+    __device__ __forceinline__ void put(int d, u32 eidx, u32 N, float W) const { PathEnt e; e.eidx = eidx; e.N = N; e.W = W; p[d] = e; }
+};
 
 // logits source for the expansion of one leaf
 struct LogitSrc {
@@ -110,9 +125,12 @@ struct LogitSrc {
 
 // M2: PUCT walk from the root; creates the child node behind the chosen unexpanded edge (env step:
 // apply + legal + terminal).  All lanes of the group return the same values.
-template <class G>
+struct LeafPos { u64 own, opp, legal; u32 info; };  // the node select created (valid when kind != terminal-revisit)
+
+template <class G, class Sink>
 __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u32 sim_idx, u32& n_nodes_g,
-                                           u32& leaf, int& kind, int& depth_out, float& tval, Cnt& c) {
+                                           u32& leaf, int& kind, int& depth_out, float& tval, Cnt& c,
+                                           const Sink& sink, LeafPos& lp) {
     constexpr int kGW = G::GW;
     Node* nodes = E.nodes + (size_t)g * E.ncap;
     Edge* edges = E.edges + (size_t)g * E.ecap;
@@ -130,31 +148,31 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u
         const int n = (int)(nd.info & 0xFFu);
         const float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
         const Edge* ed = edges + nd.edge0;
-        float bests = -__builtin_inff(); int best = 0; u32 bestN = 0, bestca = 0;
+        float bests = -__builtin_inff(), bestW = 0.0f; int best = 0; u32 bestN = 0, bestca = 0;
         for (int base = 0; base < n; base += kGW) {
             int i = base + sub;
-            float sc = -__builtin_inff(); u32 eN = 0, eca = 0;
+            float sc = -__builtin_inff(), eW = 0.0f; u32 eN = 0, eca = 0;
             if (i < n) {
                 Edge e = ed[i];
                 float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
                 float u = E.c_puct * e.P;
                 u = u * sq;
                 u = fdiv(u, 1.0f + (float)e.N);
-                sc = q + u; eN = e.N; eca = e.ca;
+                sc = q + u; eN = e.N; eca = e.ca; eW = e.W;
             }
 #pragma unroll
             for (int o = kGW / 2; o > 0; o >>= 1) {
-                float s2 = __shfl_xor(sc, o, kGW); int i2 = __shfl_xor(i, o, kGW);
+                float s2 = __shfl_xor(sc, o, kGW), w2 = __shfl_xor(eW, o, kGW); int i2 = __shfl_xor(i, o, kGW);
                 u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
                 bool take = (s2 > sc) || (s2 == sc && i2 < i);
-                if (take) { sc = s2; i = i2; eN = n2; eca = c2; }
+                if (take) { sc = s2; i = i2; eN = n2; eca = c2; eW = w2; }
             }
-            if (sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; }
+            if (sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; bestW = eW; }
         }
         if (lead) c.v[CNT_CHILD_SCORED] += (u32)n;
         u32 eidx = nd.edge0 + (u32)best;
         if (lead) {
-            if (depth < E.maxd) E.path[(size_t)depth * E.B + g] = eidx;
+            if (depth < E.maxd) sink.put(depth, eidx, bestN, bestW);
             else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
         }
         depth++;
@@ -171,10 +189,11 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u
         u64 lg = G::legal(cown, copp);
         int tv = 0;
         bool term = G::terminal(cown, copp, tm, lg, &tv);
+        lp.own = cown; lp.opp = copp; lp.legal = term ? 0 : lg;
+        lp.info = (term ? kTerm : 0u) | ((u32)(tv + 1) << 9) | ((tm == 1 ? 1u : 0u) << 11);
         if (lead) {
             Node ch;
-            ch.own = cown; ch.opp = copp; ch.legal = term ? 0 : lg; ch.edge0 = 0;
-            ch.info = (term ? kTerm : 0u) | ((u32)(tv + 1) << 9) | ((tm == 1 ? 1u : 0u) << 11);
+            ch.own = cown; ch.opp = copp; ch.legal = lp.legal; ch.edge0 = 0; ch.info = lp.info;
             nodes[id] = ch;
             edges[eidx].ca = id | ((u32)act << 24);
             c.v[CNT_ENV_STEPS]++; c.v[CNT_PATH_NODES]++;
@@ -193,8 +212,9 @@ __device__ __forceinline__ int nth_bit(u64 m, int k) {
 
 // M3: masked softmax over the legal actions (ascending), edges bump-allocated.  `legal` is the
 // leaf's legal mask (known to the caller: the root's or the node select just created).
+// `info` = the leaf's header word as created (child count 0): the header is rewritten, never re-read.
 template <class G>
-__device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal,
+__device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info,
                                            const LogitSrc& ls, u32& n_edges_g, Cnt& c) {
     constexpr int kGW = G::GW, kCH = (G::MAXCH + G::GW - 1) / G::GW;
     Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
@@ -233,8 +253,7 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
             if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(ex[k], s); e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
     }
     if (sub == 0) {
-        nd->edge0 = e0;
-        nd->info = (nd->info & ~0xFFu) | (u32)n;
+        *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);  // edge0, info: one 8-byte store
         c.v[CNT_EXPANDED]++;
         c.v[CNT_CHILD_WRITTEN] += (u32)n;
     }
@@ -242,6 +261,20 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
 }
 
 // M4: W is stored for the mover at the parent, so the sign flips every ply; one path edge per lane
+// fused search: N and W of every path edge were captured by the select walk (nothing else touches this
+// game's tree in between), so the backup is one 8-byte store per path edge, no load
+template <int kGW>
+__device__ __forceinline__ void dev_backup_lds(const EngineDev& E, int g, int sub, int depth, float v, const PathEnt* path, Cnt& c) {
+    Edge* edges = E.edges + (size_t)g * E.ecap;
+    const int dmax = depth < E.maxd ? depth : E.maxd;
+    for (int d = sub; d < dmax; d += kGW) {
+        PathEnt pe = path[d];
+        float val = ((dmax - 1 - d) & 1) ? v : -v;  // deepest edge gets -v
+        *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(pe.N + 1u, __float_as_uint(pe.W + val));
+    }
+    if (sub == 0) c.v[CNT_EDGES_BACKED] += (u32)dmax;
+}
+
 template <int kGW>
 __device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, Cnt& c) {
     Edge* edges = E.edges + (size_t)g * E.ecap;
@@ -376,16 +409,17 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
         if (do_expand && kind != LEAF_NONE) {
             u32 leaf = E.leaf_node[g];
             const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+            const u64 nlegal = nd->legal; const u32 ninfo = nd->info;
             float v;
             if (kind == LEAF_EVAL) {
                 u32 ne = E.n_edges[g];
                 size_t row = E.compact ? (size_t)E.leaf_slot[g] : (size_t)g;
                 LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + row * G::NA;
-                dev_expand<G>(E, g, sub, leaf, nd->legal, ls, ne, c);
+                dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c);
                 if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; }
                 v = E.value[row];
             } else {
-                v = (float)((int)((nd->info >> 9) & 3u) - 1);
+                v = (float)((int)((ninfo >> 9) & 3u) - 1);
             }
             dev_backup<G::GW>(E, g, sub, (int)E.depth[g], v, c);
         }
@@ -394,15 +428,17 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
             if (active) {
                 group_fence();  // edges written above are read below
                 u32 nn = E.n_nodes[g], leaf; int k2, depth; float tv;
-                dev_select<G>(E, g, sub, sim_idx, nn, leaf, k2, depth, tv, c);
-                const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+                LeafPos lpos; lpos.own = 0; lpos.opp = 0; lpos.legal = 0; lpos.info = 0;
+                PathHbm sink{E, g};
+                dev_select<G>(E, g, sub, sim_idx, nn, leaf, k2, depth, tv, c, sink, lpos);
                 if (sub == 0) {
                     E.n_nodes[g] = nn; E.leaf_node[g] = leaf; E.depth[g] = (u32)depth;
-                    u64 lo = nd->own, lp = nd->opp;
-                    E.leaf_own[g] = lo; E.leaf_opp[g] = lp;
-                    if (E.compact && k2 == LEAF_EVAL) {
-                        u32 slot = atomicAdd(&E.flags[FLAG_NEVAL + (sim_idx & 1u)], 1u);
-                        E.leaf_slot[g] = slot; E.c_own[slot] = lo; E.c_opp[slot] = lp;
+                    if (k2 == LEAF_EVAL) {  // only an evaluated leaf's position is consumed (evaluator input)
+                        E.leaf_own[g] = lpos.own; E.leaf_opp[g] = lpos.opp;
+                        if (E.compact) {
+                            u32 slot = atomicAdd(&E.flags[FLAG_NEVAL + (sim_idx & 1u)], 1u);
+                            E.leaf_slot[g] = slot; E.c_own[slot] = lpos.own; E.c_opp[slot] = lpos.opp;
+                        }
                     }
                 }
                 kind8 = (uint8_t)k2;
@@ -417,12 +453,19 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
 }
 
 // whole search in one launch for the synthetic evaluators (BASELINE cfg 2):
-// root expansion + sims x (select, expand, backup), no host round trip.
+// root expansion + sims x (select, expand, backup), no host round trip.  The dependent-access
+// chain per simulation is what bounds this kernel (every game of the batch is in flight at once,
+// one lane group per game), so it is kept as short as the data structure allows: the select path
+// lives in LDS together with the N and W it saw (backup = stores only), the created leaf's position
+// and legal mask come back from the walk in registers (expansion reads nothing), and the group's
+// store -> load ordering is a wavefront-scope fence (no wait for store round trips).
 template <class G>
 __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind) {
-    constexpr int kGW = G::GW;
+    constexpr int kGW = G::GW, kGPB = 256 / kGW;
+    __shared__ PathEnt s_path[kGPB][G::MAXD];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
+    PathEnt* mypath = s_path[threadIdx.x / kGW];
     Cnt c = {};
     if (g < E.B && E.g_state[g] == 0) {
         bool ok = true;
@@ -434,20 +477,20 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
             const u64 rown = E.g_own[g], ropp = E.g_opp[g];
             ls.h = hash_pos(rown, ropp);
             group_fence();
-            dev_expand<G>(E, g, sub, 0, G::legal(rown, ropp), ls, ne, c);
+            dev_expand<G>(E, g, sub, 0, G::legal(rown, ropp), (E.g_to_move[g] == 1 ? 1u : 0u) << 11, ls, ne, c);
+            PathLds sink{mypath};
             for (int s = 0; s < E.sims; ++s) {
                 group_fence();  // this group's stores -> its loads
                 u32 leaf; int kind, depth; float v;
-                dev_select<G>(E, g, sub, (u32)s, nn, leaf, kind, depth, v, c);
+                LeafPos lp; lp.own = 0; lp.opp = 0; lp.legal = 0; lp.info = 0;
+                dev_select<G>(E, g, sub, (u32)s, nn, leaf, kind, depth, v, c, sink, lp);
                 if (kind == LEAF_EVAL) {
-                    group_fence();
-                    const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
-                    u64 lo = nd->own, lp = nd->opp;
-                    ls.h = hash_pos(lo, lp);
-                    dev_expand<G>(E, g, sub, leaf, G::legal(lo, lp), ls, ne, c);
+                    ls.h = hash_pos(lp.own, lp.opp);
+                    dev_expand<G>(E, g, sub, leaf, lp.legal, lp.info, ls, ne, c);
                     v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
                 }
-                dev_backup<G::GW>(E, g, sub, depth, v, c);
+                group_fence();  // LDS path entries (lane 0) -> the lanes that back them up
+                dev_backup_lds<G::GW>(E, g, sub, depth, v, mypath, c);
             }
             if (sub == 0) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
         }

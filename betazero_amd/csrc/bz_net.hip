@@ -653,10 +653,8 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
 }
 
-#ifndef BZ_FP8_WAVES_PER_SIMD
-#define BZ_FP8_WAVES_PER_SIMD 2   // 67.6 KB of LDS per workgroup: two workgroups per CU hide each other's epilogues
-#endif
-__global__ void __launch_bounds__(256, BZ_FP8_WAVES_PER_SIMD) k_tower_fp8(TowerArgs T) {
+// 67.6 KB of LDS per workgroup: two workgroups per CU hide each other's epilogues (launch bound 2 waves per SIMD)
+__global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

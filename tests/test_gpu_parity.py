@@ -741,7 +741,8 @@ def test_cfg3_800_sims_bf16_net_search_close_to_oracle_bf16_emulation():
     """one 800-simulation search with the bf16 MFMA net in the loop vs the oracle running the same
     search with its bf16-emulating net (CPU threads, 8 games).  The two nets differ by ~6e-4 on the logits
     (accumulation order), so the trees may part ways late; the visit distributions must stay close:
-    total-variation distance of pi < 0.05 and the same most-visited move (measured: see the printed values)."""
+    total-variation distance of pi < 0.01 and the same most-visited move (measured on MI355X: identical
+    visit counts in all 8 games, TV = 0)."""
     import threading
     from betazero_amd.net import DeviceNet
     m = _net(128, 6, bf16=True)
@@ -768,7 +769,7 @@ def test_cfg3_800_sims_bf16_net_search_close_to_oracle_bf16_emulation():
         tv.append(0.5 * np.abs(N[g].astype(np.float64) - n.astype(np.float64)).sum() / sims)
         same += int(np.argmax(N[g]) == np.argmax(n))
     print("bf16 search vs oracle emulation: TV distance of pi per game", np.round(tv, 4), "same argmax", same, "of", B)
-    assert max(tv) < 0.05 and same >= B - 1
+    assert max(tv) < 0.01 and same == B
 
 
 def _stage_isolating_params(m, stage):
@@ -856,8 +857,8 @@ def test_reversi_score_batch_counts_vs_oracle():
     n = len(fin)
     w = torch.empty(n, dtype=torch.int8, device=DEV)
     c = torch.empty((n, 2), dtype=torch.uint8, device=DEV)
-    _lib.check(_lib.lib().bz_reversi_score_batch(_dev_u64(x).data_ptr(), _dev_u64(o).data_ptr(), n, w.data_ptr(),
-                                                 c.data_ptr(), _stream()))
+    xd, od = _dev_u64(x), _dev_u64(o)  # keep the device copies alive across the asynchronous call
+    _lib.check(_lib.lib().bz_reversi_score_batch(xd.data_ptr(), od.data_ptr(), n, w.data_ptr(), c.data_ptr(), _stream()))
     torch.cuda.synchronize()
     assert np.array_equal(w.cpu().numpy().astype(np.int64), fin[:, 2].astype(np.int64) - 1)
     assert np.array_equal(c.cpu().numpy().astype(np.int64), fin[:, 3:5].astype(np.int64))

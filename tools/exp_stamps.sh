@@ -1,3 +1,8 @@
-BZ_EXTRA_HIPCC_FLAGS="-DBZ_EXP_STAMPS $1" python betazero_amd/build.py > /dev/null 2>&1 || echo BUILD FAIL
-python tools/exp_stamps.py
-python betazero_amd/build.py > /dev/null 2>&1
+#!/bin/bash
+# In-kernel stamps (s_memtime per phase, in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz) of the
+# fused net kernel.  Builds the diagnostic variant into its OWN file (betazero_amd/libbz_hip.stamps.so);
+# the product library is not touched.  FP8=1 for the fp8 kernel.  Run on the GPU box (gpurun).
+set -e
+cd "$(dirname "$0")/.."
+SO=$(python -c "from betazero_amd import build; print(build.build_variant('stamps', ['-DBZ_EXP_STAMPS']))")
+BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 python tools/exp_stamps.py
