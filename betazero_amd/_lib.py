@@ -51,6 +51,10 @@ _SIGS = {
     "bz_reversi_legal_batch": (i32, [vp, vp, i64, vp, vp]),
     "bz_reversi_score_batch": (i32, [vp, vp, i64, vp, vp, vp]),
     "bz_ttt_step_batch": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]),
+    "bz_reversi_minimax": (i32, [u64, u64, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "bz_ttt_minimax": (i32, [u32, u32, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "bz_reversi_minimax_batch": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp]),
+    "bz_ttt_minimax_batch": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
     "bz_augment_d4_batch": (i32, [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "bz_net_update": (i32, [vp, vp, vp]),
     "bz_net_param_count": (i64, [i32, i32, i32]),

@@ -18,6 +18,8 @@
 // trajectory contract tic_tac_toe.py:13-34; canonical side-to-move states
 // generate_training_games.py:12-23.  MCTS itself is build-authored (the
 // reference has none).
+#include <stdlib.h>
+
 #include <new>
 
 #include "bz_common.h"
@@ -213,10 +215,10 @@ __device__ __forceinline__ int nth_bit(u64 m, int k) {
 // M3: masked softmax over the legal actions (ascending), edges bump-allocated.  `legal` is the
 // leaf's legal mask (known to the caller: the root's or the node select just created).
 // `info` = the leaf's header word as created (child count 0): the header is rewritten, never re-read.
-template <class G>
+template <class G, int kGW = G::GW, bool kHeader = true>
 __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info,
                                            const LogitSrc& ls, u32& n_edges_g, Cnt& c) {
-    constexpr int kGW = G::GW, kCH = (G::MAXCH + G::GW - 1) / G::GW;
+    constexpr int kCH = (G::MAXCH + kGW - 1) / kGW;
     Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
     const u32 e0 = n_edges_g;
     Edge* ed = E.edges + (size_t)g * E.ecap + e0;
@@ -253,7 +255,7 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
             if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(ex[k], s); e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
     }
     if (sub == 0) {
-        *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);  // edge0, info: one 8-byte store
+        if (kHeader) *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);  // edge0, info: one 8-byte store
         c.v[CNT_EXPANDED]++;
         c.v[CNT_CHILD_WRITTEN] += (u32)n;
     }
@@ -498,6 +500,180 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
     cnt_flush(E, c);
 }
 
+// ---- Tic-tac-toe specialisation of the fused search (BASELINE cfg 2; sims <= 120).
+// The walk is a dependent chain per game and every game of the batch is in flight at once, so the
+// time of a launch is sims x (dependent memory round trips per simulation).  Three things cut the chain:
+//  * the root's edges live in REGISTERS for the whole search (lane sub holds edges sub, sub+GW, ...): level 0
+//    of every simulation reads nothing, its backup writes nothing; the edges go to HBM once, at the end;
+//  * an edge's `ca` word also carries what the walk needs to know about the child -- its first edge, its
+//    child count, terminal flag and value -- so a level is ONE load (the child's edges), never the child's
+//    node first (TTT's numbers fit in 32 bits: child 8 | edge0 12 | n 4 | action 4 | terminal 1 | value 2);
+//  * positions are carried down the walk by applying the actions (TTT: swap + one bit), so nodes below the
+//    root are never loaded -- and, since nothing reads them, never stored.
+// Results (root statistics, counters, examples) are bit-identical to the generic kernel and the oracle; the
+// root edges are written back in the generic format, which is all that k_play / k_root_stats read.
+__device__ __forceinline__ u32 ttt_ca(u32 child, u32 edge0, u32 n, u32 act, bool term, int tv) {
+    return child | (edge0 << 8) | (n << 20) | (act << 24) | ((term ? 1u : 0u) << 28) | ((u32)(tv + 1) << 29);
+}
+constexpr int kTttFusedMaxSims = 120;
+
+__device__ __forceinline__ float puct_score(const Edge& e, float c_puct, float sq) {
+    float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
+    float u = c_puct * e.P;
+    u = u * sq;
+    u = fdiv(u, 1.0f + (float)e.N);
+    return q + u;
+}
+
+template <int kGW>
+__global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_kind) {
+    using G = TicTacToe;
+    constexpr int kGPB = 256 / kGW, kCH = (G::MAXCH + kGW - 1) / kGW;
+    __shared__ PathEnt s_path[kGPB][G::MAXD];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t / kGW, sub = t % kGW;
+    PathEnt* mypath = s_path[threadIdx.x / kGW];
+    Cnt c = {};
+    if (g < E.B && E.g_state[g] == 0) {
+        bool ok = true;
+        if (sub == 0) ok = dev_root_init<G>(E, g);
+        ok = __shfl((int)ok, 0, kGW) != 0;
+        if (ok) {
+            Edge* edges = E.edges + (size_t)g * E.ecap;
+            const bool lead = sub == 0;
+            u32 nn = 1, ne = 0;
+            LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
+            const u64 rown = E.g_own[g], ropp = E.g_opp[g];
+            const int rtm = E.g_to_move[g];
+            ls.h = hash_pos(rown, ropp);
+            group_fence();
+            dev_expand<G, kGW, true>(E, g, sub, 0, G::legal(rown, ropp), (rtm == 1 ? 1u : 0u) << 11, ls, ne, c);
+            group_fence();
+            const int rn = (int)ne;  // the root's children (>= 1: a terminal root was refused above)
+            Edge re[kCH];
+#pragma unroll
+            for (int k = 0; k < kCH; ++k) {
+                const int i = sub + kGW * k;
+                if (i < rn) re[k] = edges[i];
+                else { re[k].N = 0; re[k].W = 0.0f; re[k].P = 0.0f; re[k].ca = 0; }
+            }
+            for (int s = 0; s < E.sims; ++s) {
+                group_fence();  // this group's stores of the previous simulation -> its loads
+                // ---- level 0 from registers
+                float bests = -__builtin_inff(), bestW = 0.0f; int best = 0; u32 bestN = 0, bestca = 0;
+                {
+                    const float sq = fsqrt((float)(s > 1 ? s : 1));
+#pragma unroll
+                    for (int k = 0; k < kCH; ++k) {
+                        int i = sub + kGW * k;
+                        float sc = i < rn ? puct_score(re[k], E.c_puct, sq) : -__builtin_inff();
+                        float eW = re[k].W; u32 eN = re[k].N, eca = re[k].ca;
+#pragma unroll
+                        for (int o = kGW / 2; o > 0; o >>= 1) {
+                            float s2 = __shfl_xor(sc, o, kGW), w2 = __shfl_xor(eW, o, kGW); int i2 = __shfl_xor(i, o, kGW);
+                            u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
+                            bool take = (s2 > sc) || (s2 == sc && i2 < i);
+                            if (take) { sc = s2; i = i2; eN = n2; eca = c2; eW = w2; }
+                        }
+                        if (sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; bestW = eW; }
+                    }
+                }
+                if (lead) { c.v[CNT_SIMS]++; c.v[CNT_PATH_NODES]++; c.v[CNT_CHILD_SCORED] += (u32)rn; }
+                const int i0 = best; const u32 N0 = bestN; const float W0 = bestW;
+                int depth = 1;
+                u64 own = rown, opp = ropp; int tm = rtm;
+                u32 ca = bestca, parentN = bestN, pe_idx = (u32)best, new_ca = 0;
+                bool made = false;
+                float v = 0.0f;
+                for (;;) {  // walk below the root: `ca` is the edge just chosen
+                    const int act = (int)((ca >> 24) & 0xFu);
+                    u64 cown, copp;
+                    G::apply(own, opp, act, &cown, &copp);
+                    own = cown; opp = copp; tm = -tm;
+                    if (ca & 0xFFu) {  // the child exists
+                        if (lead) c.v[CNT_PATH_NODES]++;
+                        if ((ca >> 28) & 1u) { v = (float)((int)((ca >> 29) & 3u) - 1); break; }  // terminal, revisited
+                        const u32 e0 = (ca >> 8) & 0xFFFu; const int n = (int)((ca >> 20) & 0xFu);
+                        const u32 sumN = parentN - 1u;  // visits of the child's edges = visits into it minus the creating one
+                        const float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
+                        const Edge* ed = edges + e0;
+                        bests = -__builtin_inff(); best = 0; bestN = 0; bestca = 0; bestW = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < kCH; ++k) {
+                            int i = sub + kGW * k;
+                            float sc = -__builtin_inff(), eW = 0.0f; u32 eN = 0, eca = 0;
+                            if (i < n) { Edge e = ed[i]; sc = puct_score(e, E.c_puct, sq); eN = e.N; eca = e.ca; eW = e.W; }
+#pragma unroll
+                            for (int o = kGW / 2; o > 0; o >>= 1) {
+                                float s2 = __shfl_xor(sc, o, kGW), w2 = __shfl_xor(eW, o, kGW); int i2 = __shfl_xor(i, o, kGW);
+                                u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
+                                bool take = (s2 > sc) || (s2 == sc && i2 < i);
+                                if (take) { sc = s2; i = i2; eN = n2; eca = c2; eW = w2; }
+                            }
+                            if (kGW * k < n && sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; bestW = eW; }
+                        }
+                        pe_idx = e0 + (u32)best;
+                        if (lead) {
+                            c.v[CNT_CHILD_SCORED] += (u32)n;
+                            if (depth < E.maxd) { PathEnt pe; pe.eidx = pe_idx; pe.N = bestN; pe.W = bestW; mypath[depth] = pe; }
+                            else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
+                        }
+                        depth++;
+                        ca = bestca; parentN = bestN;
+                        continue;
+                    }
+                    // create the child behind the chosen edge (env step) and, unless terminal, expand it at once
+                    const u32 id = nn++;
+                    const u64 lg = G::legal(own, opp);
+                    int tv = 0;
+                    const bool term = G::terminal(own, opp, tm, lg, &tv);
+                    if (lead) { c.v[CNT_ENV_STEPS]++; c.v[CNT_PATH_NODES]++; }
+                    if (term) {
+                        new_ca = ttt_ca(id, 0, 0, (u32)act, true, tv);
+                        v = (float)tv;
+                    } else {
+                        ls.h = hash_pos(own, opp);
+                        const u32 e0 = ne;
+                        dev_expand<G, kGW, false>(E, g, sub, id, lg, 0, ls, ne, c);
+                        new_ca = ttt_ca(id, e0, ne - e0, (u32)act, false, 0);
+                        v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
+                    }
+                    made = true;
+                    break;
+                }
+                if (made && depth > 1 && lead) edges[pe_idx].ca = new_ca;  // (depth 1: the parent edge is a root register)
+                // ---- backup: root edge in registers, deeper edges by one 8-byte store each from the LDS path
+                const int dmax = depth < E.maxd ? depth : E.maxd;
+                {
+                    const float val0 = ((dmax - 1) & 1) ? v : -v;
+#pragma unroll
+                    for (int k = 0; k < kCH; ++k)
+                        if (sub + kGW * k == i0) {
+                            re[k].N = N0 + 1u; re[k].W = W0 + val0;
+                            if (made && depth == 1) re[k].ca = new_ca;
+                        }
+                }
+                group_fence();  // the lead lane's LDS path entries -> the lanes that back them up
+                for (int d = sub; d < dmax; d += kGW) {
+                    if (d == 0) continue;
+                    PathEnt pe = mypath[d];
+                    float val = ((dmax - 1 - d) & 1) ? v : -v;
+                    *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(pe.N + 1u, __float_as_uint(pe.W + val));
+                }
+                if (lead) c.v[CNT_EDGES_BACKED] += (u32)dmax;
+            }
+            // root edges back to HBM in the generic format (child | action << 24): what k_play / k_root_stats read
+#pragma unroll
+            for (int k = 0; k < kCH; ++k) {
+                const int i = sub + kGW * k;
+                if (i < rn) { Edge e = re[k]; e.ca = (e.ca & 0xFFu) | (((e.ca >> 24) & 0xFu) << 24); edges[i] = e; }
+            }
+            if (lead) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
+        }
+    }
+    cnt_flush(E, c);
+}
+
 template <class G>
 __global__ void __launch_bounds__(256) k_root_stats(EngineDev E) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -591,6 +767,7 @@ struct bz_engine {
     bz_net* net;
     int64_t bytes;
     int pack_parity;  // which NEVAL buffer the last root_begin / select packed into
+    int ttt_gw;       // lanes per game of the TTT-specialised fused search (4; BZ_TTT_GW=2|4|8 for tuning runs, 0 = generic kernel)
 };
 
 namespace {
@@ -638,7 +815,7 @@ Offsets carve(const bz_engine_cfg& c) {
     o.ex_meta = k.take(256);
     o.root_N = k.take(B * o.na * 4); o.root_W = k.take(B * o.na * 4); o.root_P = k.take(B * o.na * 4);
     o.counters = k.take(16 * 8);
-    o.n_cnt_slots = (int)((B * 16 + 63) / 64) + 4;  // one slot per wave of the widest (group) launch
+    o.n_cnt_slots = (int)((B * 16 + 63) / 64) + 4;  // one slot per wave of the widest (group) launch (<= 16 lanes per game)
     o.cnt_slots = k.take((int64_t)o.n_cnt_slots * CNT_N * 8);
     o.flags = k.take(FLAG_N * 4);
     o.total = k.off;
@@ -681,6 +858,8 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
     e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1;
+    e->ttt_gw = 4;
+    if (const char* gw = getenv("BZ_TTT_GW")) { int v = atoi(gw); if (v == 0 || v == 2 || v == 4 || v == 8) e->ttt_gw = v; }
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
@@ -812,6 +991,16 @@ BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     int ek = e->cfg.eval_kind;
     if (ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) {
         ProfScope ps(BZ_PROF_SEARCH_FUSED, stream);
+        if (e->cfg.game == BZ_GAME_TTT && e->cfg.sims <= kTttFusedMaxSims && e->ttt_gw > 0) {
+            const dim3 grid = grid_groups(e->dev.B, e->ttt_gw);
+            switch (e->ttt_gw) {
+            case 2: hipLaunchKernelGGL(k_search_fused_ttt<2>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
+            case 8: hipLaunchKernelGGL(k_search_fused_ttt<8>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
+            default: hipLaunchKernelGGL(k_search_fused_ttt<4>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
+            }
+            BZ_LAUNCH_CHECK("k_search_fused_ttt");
+            return BZ_OK;
+        }
         BZ_DISPATCH_G(e, k_search_fused, stream, e->dev, ek);
         return BZ_OK;
     }

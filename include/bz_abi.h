@@ -124,6 +124,30 @@ int32_t bz_augment_d4_batch(const uint64_t* own, const uint64_t* opp, const floa
                             int32_t na, uint64_t* own8, uint64_t* opp8, float* pi8, uint64_t* key8, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* The reference's minimax players (the arena's yard-stick, SURVEY.md 8(f)   */
+/* row 3), one game per lane, and as scalar host entry points.               */
+/* ------------------------------------------------------------------------ */
+/* OptimalPlayer.minimax  src/reversi/players/reversi_players.py:41-69 with evaluate_board :71-77:
+ * depth-limited (0 <= max_depth <= 8), stone difference for the player, moves in
+ * generate_possible_moves order, first strictly better score wins, no pass rule inside the
+ * search (a side without a move in an unfinished game scores -inf / +inf: the reference's
+ * behaviour).  self = the player's stones, other = the opponent's; the player is to move.
+ * *move = bit index 8*row+col, or -1 where the reference's best_move is None (get_move then
+ * draws random.choice, :38-39 -- left to the caller); *score = the root value (+-1000 = +-inf). */
+int32_t bz_reversi_minimax(uint64_t self, uint64_t other, int32_t size, int32_t max_depth, int32_t* move,
+                           int32_t* score);
+/* OptimalPlayer.minimax  src/tic_tac_toe/players.py:41-70 (full depth; +1/0/-1 for the player).
+ * symbol = the player's colour (+1 = X), needed only for is_game_over's X-before-O test order.
+ * *move = 3*row+col, -1 = None (finished board), -2 = empty board (the reference plays a random
+ * opening move there, :35-36 -- left to the caller). */
+int32_t bz_ttt_minimax(uint32_t self, uint32_t other, int32_t symbol, int32_t* move, int32_t* score);
+/* batched: device arrays [n]; active (optional, may be null): 0 = skip the game (move -1) */
+int32_t bz_reversi_minimax_batch(const uint64_t* self, const uint64_t* other, const uint8_t* active, int64_t n,
+                                 int32_t size, int32_t max_depth, int8_t* move, int16_t* score, void* stream);
+int32_t bz_ttt_minimax_batch(const uint16_t* self, const uint16_t* other, const int8_t* symbol,
+                             const uint8_t* active, int64_t n, int8_t* move, int16_t* score, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Policy/value net (build-authored architecture, SURVEY.md 8(d) "net";      */
 /* the calling convention generalises AIPlayer.get_move players.py:84-98:    */
 /* side-to-move canonical input, logits out, legality masked by the caller)  */

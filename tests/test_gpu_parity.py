@@ -865,3 +865,39 @@ def test_reversi_score_batch_counts_vs_oracle():
     for i in range(0, n, 17):
         ws, (nx, no) = orc.reversi_score(int(x[i]), int(o[i]))
         assert (ws, nx, no) == (int(w[i]), int(c[i, 0]), int(c[i, 1]))
+
+
+@pytest.mark.parametrize("gw", ["2", "4", "8"])
+def test_ttt_specialised_fused_search_equals_generic_kernel_and_oracle(gw, monkeypatch):
+    """the TTT-specialised fused search (root edges in registers, child header packed into the edge word, no
+    node loads below the root; lanes per game = 2, 4 or 8) against the generic fused kernel (BZ_TTT_GW=0) and the
+    oracle: root N/W/P, every work counter and complete games, bit for bit, from random reachable positions"""
+    d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
+    pos = d["pos"]
+    live = pos[pos[:, 4] == 0]  # not game-over
+    rng = np.random.default_rng(int(gw))
+    sel = live[rng.choice(len(live), 500, replace=False)]
+    tm = np.where(sel[:, 2] == 1, 1, -1).astype(np.int8)
+    own = np.where(tm == 1, sel[:, 0], sel[:, 1]).astype(np.uint64)
+    opp = np.where(tm == 1, sel[:, 1], sel[:, 0]).astype(np.uint64)
+    out = {}
+    for mode in (gw, "0"):
+        monkeypatch.setenv("BZ_TTT_GW", mode)
+        for ev, sims in (("hash", 120), ("uniform", 50)):
+            eng = _engine("ttt", len(sel), sims, ev)
+            eng.set_roots(own, opp, tm)
+            eng.reset_counters()
+            eng.search()
+            N, W, P = eng.root_stats()
+            eng.status()
+            out[(mode, ev)] = (N, W.view(np.uint32), P.view(np.uint32), eng.counters())
+    for ev, sims in (("hash", 120), ("uniform", 50)):
+        a, b = out[(gw, ev)], out[("0", ev)]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert a[3] == b[3], (a[3], b[3])
+        for g in range(0, len(sel), 25):
+            n, w, p, _ = orc.mcts_search(orc.GAME_TTT, int(own[g]), int(opp[g]), int(tm[g]), sims,
+                                         orc.EVAL_HASH if ev == "hash" else orc.EVAL_UNIFORM)
+            assert np.array_equal(a[0][g], n) and np.array_equal(a[1][g], w.view(np.uint32))
+    monkeypatch.setenv("BZ_TTT_GW", gw)
+    _check_selfplay("ttt", 96, 40, "hash", 4, 0, 7, base=300)
