@@ -363,7 +363,8 @@ __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, 
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     E.g_own[g] = own[g]; E.g_opp[g] = opp[g]; E.g_to_move[g] = tm[g];
-    E.g_state[g] = 0; E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
+    E.g_state[g] = tm[g] == 0 ? 1 : 0;  // to_move 0 = slot not in use (the arena searches a subset of its games)
+    E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
     if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0; }
 }
 
@@ -858,7 +859,9 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
     e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1;
-    e->ttt_gw = 4;
+    // measured on MI355X at 65,536 games x 50 sims (profiles/r02_cfg2_*): 2 lanes 0.185 ms, 4 lanes 0.190 ms, 8 lanes
+    // 0.294 ms per launch; small batches keep 4 lanes so that the chip still sees a few waves per CU
+    e->ttt_gw = cfg->n_games >= 32768 ? 2 : 4;
     if (const char* gw = getenv("BZ_TTT_GW")) { int v = atoi(gw); if (v == 0 || v == 2 || v == 4 || v == 8) e->ttt_gw = v; }
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;

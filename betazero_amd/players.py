@@ -66,6 +66,56 @@ class MinimaxPlayer(Player):
         return res
 
 
+class OptimalPlayer(Player):
+    """The reference's tic-tac-toe OptimalPlayer (src/tic_tac_toe/players.py:30-70) on the library's
+    minimax (bz_ttt_minimax: the host build of the code the arena kernel runs): random opening move on an
+    empty board, otherwise the first move with the best full-depth minimax score."""
+
+    def __init__(self, symbol):
+        self.symbol = symbol
+
+    def minimax(self, board, is_maximizing=True):
+        """(score, move) for `symbol` to move -- the reference's minimax(board, True)"""
+        import ctypes as C
+        from . import _lib
+        assert is_maximizing, "only the root call minimax(board, True) is mirrored"
+        own, opp = board.bits(self.symbol)
+        mv, sc = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().bz_ttt_minimax(own, opp, self.symbol, C.byref(mv), C.byref(sc)))
+        return sc.value, (None if mv.value < 0 else (mv.value // 3, mv.value % 3))
+
+    def get_move(self, board):
+        moves = board.generate_possible_moves()
+        if len(moves) == 9:
+            return random.choice(moves)
+        return self.minimax(board, True)[1]
+
+
+class ReversiOptimalPlayer(ReversiPlayer):
+    """The reference's Reversi OptimalPlayer (src/reversi/players/reversi_players.py:35-77): depth-limited
+    minimax on the stone difference, no pass rule inside the search, random.choice when no move scores above
+    -inf -- on bz_reversi_minimax (0 <= max_depth <= 8)."""
+
+    def __init__(self, symbol, max_depth=4):
+        self.symbol, self.max_depth = symbol, max_depth
+
+    def minimax(self, board, is_maximizing=True, depth=0):
+        import ctypes as C
+        from . import _lib
+        assert is_maximizing and depth == 0, "only the root call minimax(board, True, 0) is mirrored"
+        own, opp = board.bits(self.symbol)
+        mv, sc = C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().bz_reversi_minimax(own, opp, board.size, self.max_depth, C.byref(mv), C.byref(sc)))
+        score = float("inf") if sc.value >= 1000 else (float("-inf") if sc.value <= -1000 else sc.value)
+        return score, (None if mv.value < 0 else (mv.value // 8, mv.value % 8))
+
+    def get_move(self, board):
+        _, best_move = self.minimax(board, True, 0)
+        if best_move is None:
+            return random.choice(board.generate_possible_moves(self.symbol))
+        return best_move
+
+
 class MCTSPlayer(Player):
     """get_move(board) -> (row, col) by one GPU search (PUCT, `sims` simulations)
     from `board` with `symbol` to move; plays argmax visit count (ties -> lowest

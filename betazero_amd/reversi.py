@@ -1,6 +1,10 @@
 """API-compatible ReversiBoard (reference: src/reversi/game_logic/reversi_board.py:4-88)
 backed by bitboards + libbz_hip.so's scalar rule entry points, and a headless
-mirror of the reference's turn loop (reversi_terminal.py:16-38)."""
+mirror of the reference's turn loop (reversi_terminal.py:16-38).
+
+Provenance note: `__str__` and the two strings printed by `get_score(print_result=True)` reproduce the
+reference's text (reversi_board.py:16-20, 78-83) verbatim, because that text is observable output of the
+API; everything else in this file is this build's own."""
 import ctypes as C
 
 import numpy as np

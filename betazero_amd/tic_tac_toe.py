@@ -1,6 +1,11 @@
 """API-compatible TicTacToeBoard (reference: src/tic_tac_toe/tic_tac_toe_board.py:4-43),
 TicTacToeHeadless (tic_tac_toe.py:6-34) and process_game_positions
-(SL/generate_training_games.py:12-23)."""
+(SL/generate_training_games.py:12-23).
+
+Provenance note: this file is the API contract itself, so two pieces follow the reference's text line for
+line on purpose -- `__str__` (tic_tac_toe_board.py:7-15: the printed board is observable output) and the
+turn loop of `TicTacToeHeadless.play` (tic_tac_toe.py:13-34: the trajectory the data generator consumes).
+Everything else (bitboard state, rule calls through the C ABI) is this build's own."""
 import ctypes as C
 
 import numpy as np

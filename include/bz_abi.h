@@ -235,7 +235,8 @@ int32_t bz_engine_get_layout(const bz_engine* e, bz_engine_layout* out);
 int32_t bz_engine_set_net(bz_engine* e, bz_net* net);
 /* start every slot at the game's start position (round 0) */
 int32_t bz_engine_reset_games(bz_engine* e, void* stream);
-/* load arbitrary root positions (MCTSPlayer.get_move, tests): device arrays [B] */
+/* load arbitrary root positions (MCTSPlayer.get_move, the arena, tests): device arrays [B];
+ * to_move[g] = +1 / -1 (absolute colour of the mover) or 0 = leave slot g idle in this search */
 int32_t bz_engine_set_roots(bz_engine* e, const uint64_t* own, const uint64_t* opp,
                             const int8_t* to_move, void* stream);
 /* one full search (root expansion + cfg.sims simulations) for every active slot */

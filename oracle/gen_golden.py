@@ -16,6 +16,8 @@ Fixtures:
   F7 mcts_twin.npz / .json      build-authored MCTS twin over the REFERENCE's
                                 board classes (every env transition inside the
                                 search is reference-computed)
+  F9 minimax_players.npz        decisions of the reference's OptimalPlayer classes
+                                (Reversi depth-limited minimax, TTT full minimax)
 
 Run:  python oracle/gen_golden.py
 """
@@ -353,8 +355,101 @@ def gen_f8():
     print("F8", len(st), "augmented rows")
 
 
+# ---------------------------------------------------------------- F9: the reference's minimax players
+def _load_by_path(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_f9():
+    """decisions of the reference's OptimalPlayer classes (the arena's yard-stick):
+    Reversi  reversi_players.py:35-77  minimax(board, True, 0) -> (score, best_move) on positions of seeded random
+             games, sizes 4/6/8, depths 1..5 (deeper on the small boards), both colours;
+    TTT      players.py:30-70          minimax(board, True) on every reachable, unfinished position for the side
+             to move.  +-inf scores are stored as +-1000, best_move None as -1."""
+    rp = _load_by_path("ref_reversi_players", os.path.join(REF, "src/reversi/players/reversi_players.py"))
+    tp = _load_by_path("ref_ttt_players", os.path.join(REF, "src/tic_tac_toe/players.py"))
+    rng = random.Random(99)
+    rows = []  # size, depth, symbol, x, o, move (8r+c | -1), score
+    plan = {4: [(1, 10), (2, 10), (3, 10), (4, 10), (5, 8), (6, 6)], 6: [(1, 12), (2, 12), (3, 10), (4, 6)],
+            8: [(1, 14), (2, 12), (3, 10), (4, 4)]}
+    for size, lst in plan.items():
+        for depth, count in lst:
+            got = 0
+            while got < count:
+                b, cur = ReversiBoard(size=size), 1
+                target = rng.randrange(0, size * size - 4)
+                for _ in range(target):
+                    mv = b.generate_possible_moves(cur)
+                    if not mv:
+                        cur = -cur
+                        mv = b.generate_possible_moves(cur)
+                        if not mv:
+                            break
+                    b = b.make_move(*rng.choice(mv), cur)
+                    cur = -cur
+                sym = rng.choice((1, -1))
+                if b.is_game_over():
+                    continue
+                score, mv = rp.OptimalPlayer(sym, max_depth=depth).minimax(b, True, 0)
+                sc = 1000 if score == float("inf") else (-1000 if score == float("-inf") else int(score))
+                rows.append((size, depth, sym + 1, rev_bits(b.board, 1), rev_bits(b.board, -1),
+                             255 if mv is None else 8 * mv[0] + mv[1], sc + 2000))
+                got += 1
+    rev = np.array(rows, dtype=np.uint64)
+    # one complete 6x6 game, OptimalPlayer(depth 2) as X against OptimalPlayer(depth 3) as O, through the reference's
+    # own turn loop semantics (reversi_terminal.py:16-38)
+    random.seed(7)
+    pl = {1: rp.OptimalPlayer(1, max_depth=2), -1: rp.OptimalPlayer(-1, max_depth=3)}
+    b, cur, seq = ReversiBoard(size=6), 1, []
+    over = False
+    while not over:
+        if b.generate_possible_moves(cur):
+            r, c = pl[cur].get_move(b)
+            seq.append((cur + 1, 8 * r + c))
+            b = b.make_move(r, c, cur)
+        over = b.is_game_over()
+        cur = -cur
+    game = np.array(seq, dtype=np.int64)
+    final = np.array([rev_bits(b.board, 1), rev_bits(b.board, -1)], dtype=np.uint64)
+    # TTT: every reachable unfinished position, for the side to move
+    seen, order = {}, []
+
+    def rec(t, cur):
+        key = (ttt_bits(t.board, 1), ttt_bits(t.board, -1))
+        if key in seen:
+            return
+        seen[key] = cur
+        order.append(key)
+        if t.is_game_over()[0]:
+            return
+        for mv in t.generate_possible_moves():
+            rec(t.make_move(*mv, cur), -cur)
+    rec(TicTacToeBoard(), 1)
+    trows = []
+    memo = {}
+    for (x, o) in order:
+        cur = seen[(x, o)]
+        t = TicTacToeBoard()
+        for i in range(9):
+            if x >> i & 1:
+                t.board[i // 3][i % 3] = 1
+            if o >> i & 1:
+                t.board[i // 3][i % 3] = -1
+        if t.is_game_over()[0] or (x | o) == 0:
+            continue
+        score, mv = tp.OptimalPlayer(cur).minimax(t, True)
+        trows.append((x, o, cur + 1, 3 * mv[0] + mv[1], score + 1))
+    ttt = np.array(trows, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "minimax_players.npz"), reversi=rev, game6=game, game6_final=final, ttt=ttt)
+    print("F9", rev.shape, game.shape, ttt.shape)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8", "f9"]
     if "f1" in which: gen_f1()
     if "f2" in which: gen_f2()
     if "f3" in which: gen_f3()
@@ -362,3 +457,4 @@ if __name__ == "__main__":
     if "f5" in which: gen_f5_f6()
     if "f7" in which: gen_f7()
     if "f8" in which: gen_f8()
+    if "f9" in which: gen_f9()

@@ -456,21 +456,91 @@ def test_training_step_closes_the_loop():
     assert np.abs(after - olg).max() < 2e-3
 
 
-def test_arena_mcts_never_loses_to_minimax_at_tictactoe():
-    """the in-repo strength yard-stick.  MCTS (5000 sims, uniform priors, v = 0 at
-    non-terminal leaves, so it learns from terminal nodes only) against full-depth minimax, both
-    colours: tic-tac-toe is a draw under best play, so MCTS must never lose."""
-    import random
-    import betazero_amd as bz
-    random.seed(1)
-    res = []
-    for k in range(8):  # (with 800 simulations the averaging backup still loses about 1 game in 12 as O)
-        m = bz.MCTSPlayer(1 if k % 2 == 0 else -1, sims=5000, evaluator="uniform")
-        o = bz.MinimaxPlayer(-m.symbol)
-        p1, p2 = (m, o) if m.symbol == 1 else (o, m)
-        _, winner = bz.TicTacToeHeadless(p1, p2).play()
-        res.append(winner * m.symbol)
-    assert min(res) >= 0, res
+def test_minimax_kernels_match_the_reference_fixture():
+    """the arena's opponent kernels (one game per lane) against fixture F9 = decisions of the reference's
+    OptimalPlayer classes (reversi_players.py:35-77, players.py:30-70), generated by importing them"""
+    d = np.load(os.path.join(G, "minimax_players.npz"))
+    rows = d["reversi"]
+    L = _lib.lib()
+    for size in (4, 6, 8):
+        for depth in sorted(set(rows[rows[:, 0] == size][:, 1].tolist())):
+            r = rows[(rows[:, 0] == size) & (rows[:, 1] == depth)]
+            sym = r[:, 2].astype(np.int64) - 1
+            own = np.where(sym == 1, r[:, 3], r[:, 4]).astype(np.uint64)
+            opp = np.where(sym == 1, r[:, 4], r[:, 3]).astype(np.uint64)
+            n = len(r)
+            od, pd_ = _dev_u64(own), _dev_u64(opp)
+            mv = torch.empty(n, dtype=torch.int8, device=DEV)
+            sc = torch.empty(n, dtype=torch.int16, device=DEV)
+            _lib.check(L.bz_reversi_minimax_batch(od.data_ptr(), pd_.data_ptr(), None, n, size, depth, mv.data_ptr(),
+                                                  sc.data_ptr(), _stream()))
+            torch.cuda.synchronize()
+            exp_mv = np.where(r[:, 5] == 255, -1, r[:, 5].astype(np.int64))
+            assert np.array_equal(mv.cpu().numpy().astype(np.int64), exp_mv), (size, depth)
+            assert np.array_equal(sc.cpu().numpy().astype(np.int64), r[:, 6].astype(np.int64) - 2000), (size, depth)
+    t = d["ttt"]
+    cur = t[:, 2] - 1
+    own = torch.as_tensor(np.where(cur == 1, t[:, 0], t[:, 1]).astype(np.int16)).to(DEV)
+    opp = torch.as_tensor(np.where(cur == 1, t[:, 1], t[:, 0]).astype(np.int16)).to(DEV)
+    symd = torch.as_tensor(cur.astype(np.int8)).to(DEV)
+    act = torch.ones(len(t), dtype=torch.uint8, device=DEV)
+    act[::7] = 0  # masked-out games report "no move"
+    mv = torch.empty(len(t), dtype=torch.int8, device=DEV)
+    sc = torch.empty(len(t), dtype=torch.int16, device=DEV)
+    _lib.check(L.bz_ttt_minimax_batch(own.data_ptr(), opp.data_ptr(), symd.data_ptr(), act.data_ptr(), len(t),
+                                      mv.data_ptr(), sc.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+    on = act.cpu().numpy() == 1
+    assert np.array_equal(mv.cpu().numpy()[on].astype(np.int64), t[on, 3]) and (mv.cpu().numpy()[~on] == -1).all()
+    assert np.array_equal(sc.cpu().numpy()[on].astype(np.int64), t[on, 4] - 1)
+
+
+def test_arena_batched_mcts_never_loses_to_minimax_at_tictactoe():
+    """SURVEY 8(f) row 3, batched: 64 concurrent games of MCTS (5000 sims, uniform priors, v = 0 at non-terminal
+    leaves, so it learns from terminal nodes only) against the reference's full-depth minimax (kernel), MCTS as X in
+    half of them and as O in the other half: tic-tac-toe is a draw under best play, so MCTS must never lose.
+    (At 800 simulations the averaging backup still loses about 1 game in 12 as O.)"""
+    from betazero_amd.arena import play_arena
+    res = play_arena("ttt", 64, 5000, evaluator="uniform", seed=1)
+    s = res.summary()
+    print("ttt arena:", s)
+    assert s["losses"] == 0 and s["games"] == 64 and (res.plies >= 5).all() and (res.plies <= 9).all()
+    assert set(res.mcts_colour.tolist()) == {1, -1}
+
+
+def test_arena_batched_reversi_mcts_vs_depth_limited_minimax():
+    """64 concurrent 8x8 games, MCTS (300 sims, hash evaluator -- there is no trained net in this repo, so no
+    strength is asserted) vs the reference's OptimalPlayer at depth 2 (kernel): every game must be a legal game of
+    Reversi by the oracle's rules with the winner the oracle computes, and every minimax move must equal the
+    scalar library call on that position."""
+    import ctypes as C
+    from betazero_amd.arena import play_arena
+    B = 64
+    res = play_arena("reversi", B, 300, opponent_depth=2, evaluator="hash", seed=5)
+    print("reversi arena (untrained evaluator):", res.summary())
+    L = _lib.lib()
+    for g in range(0, B, 5):
+        x, o, cur = 0x0000001008000000, 0x0000000810000000, 1  # reversi_board.py:9-11 (+1 on the main diagonal)
+        for act, mover in res.moves:
+            if mover[g] == 0:
+                continue
+            assert mover[g] == cur
+            own, opp = (x, o) if cur == 1 else (o, x)
+            a = int(act[g])
+            assert orc.reversi_legal(own, opp) >> a & 1
+            if cur != res.mcts_colour[g]:  # the minimax side: same decision as the scalar entry point
+                mv, sc = C.c_int32(), C.c_int32()
+                _lib.check(L.bz_reversi_minimax(own, opp, 8, 2, C.byref(mv), C.byref(sc)))
+                assert mv.value == a or mv.value == -1
+            no, np_, _ = orc.reversi_apply(own, opp, 8, a >> 3, a & 7)
+            x, o = (no, np_) if cur == 1 else (np_, no)
+            if orc.reversi_game_over(x, o):
+                break
+            cur = -cur
+            own, opp = (x, o) if cur == 1 else (o, x)
+            if orc.reversi_legal(own, opp) == 0:  # pass rule, reversi_terminal.py:31-35
+                cur = -cur
+        assert orc.reversi_game_over(x, o) and orc.reversi_score(x, o)[0] == res.winner[g]
 
 
 def test_net_fp8_mfma_vs_oracle_fp8_emulation():

@@ -1,0 +1,98 @@
+"""The reference's minimax players (arena yard-stick) through the C ABI's scalar entry
+points -- the host build of the exact code the arena kernels run -- against fixture F9, which was generated
+by IMPORTING the reference's OptimalPlayer classes (oracle/gen_golden.py gen_f9)."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+
+import betazero_amd as bz
+from betazero_amd import _lib
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rev(x, o, size, depth):
+    mv, sc = C.c_int32(), C.c_int32()
+    _lib.check(_lib.lib().bz_reversi_minimax(x, o, size, depth, C.byref(mv), C.byref(sc)))
+    return mv.value, sc.value
+
+
+def test_reversi_minimax_matches_reference_optimal_player():
+    d = np.load(os.path.join(G, "minimax_players.npz"))
+    rows = d["reversi"]
+    assert len(rows) >= 120 and set(rows[:, 0].tolist()) == {4, 6, 8}
+    n_none = n_inf = 0
+    for size, depth, sym1, x, o, move, score in rows.tolist():
+        sym = sym1 - 1
+        own, opp = (x, o) if sym == 1 else (o, x)
+        mv, sc = _rev(own, opp, size, depth)
+        exp_mv = -1 if move == 255 else move
+        assert (mv, sc) == (exp_mv, score - 2000), (size, depth, sym, hex(x), hex(o))
+        n_none += exp_mv == -1
+        n_inf += abs(score - 2000) == 1000
+    print("fixture rows", len(rows), "best_move None:", n_none, "+-inf scores:", n_inf)
+
+
+def test_reversi_optimal_player_class_replays_the_reference_game():
+    """OptimalPlayer(depth 2) as X vs OptimalPlayer(depth 3) as O on 6x6 through the reference's turn-loop
+    semantics: the same move sequence and the same final board as the reference produced (random.seed(7))."""
+    d = np.load(os.path.join(G, "minimax_players.npz"))
+    random.seed(7)
+    pl = {1: bz.ReversiOptimalPlayer(1, max_depth=2), -1: bz.ReversiOptimalPlayer(-1, max_depth=3)}
+    b, cur, seq, over = bz.ReversiBoard(size=6), 1, [], False
+    while not over:
+        if b.generate_possible_moves(cur):
+            r, c = pl[cur].get_move(b)
+            seq.append((cur + 1, 8 * r + c))
+            b = b.make_move(r, c, cur)
+        over = b.is_game_over()
+        cur = -cur
+    assert np.array_equal(np.array(seq, dtype=np.int64), d["game6"])
+    assert b.bits(1) == tuple(int(v) for v in d["game6_final"])
+    p = bz.ReversiOptimalPlayer(1, 4)  # the API of the reference class: minimax(board, True, 0) -> (score, move)
+    score, mv = p.minimax(bz.ReversiBoard(size=4), True, 0)
+    assert mv in bz.ReversiBoard(size=4).generate_possible_moves(1) and isinstance(score, int)
+
+
+def test_ttt_minimax_matches_reference_optimal_player_on_every_position():
+    d = np.load(os.path.join(G, "minimax_players.npz"))
+    rows = d["ttt"]
+    assert len(rows) == 4519  # every reachable, unfinished, non-empty position
+    mv, sc = C.c_int32(), C.c_int32()
+    L = _lib.lib()
+    for x, o, cur1, move, score1 in rows.tolist():
+        cur = cur1 - 1
+        own, opp = (x, o) if cur == 1 else (o, x)
+        _lib.check(L.bz_ttt_minimax(own, opp, cur, C.byref(mv), C.byref(sc)))
+        assert (mv.value, sc.value) == (move, score1 - 1), (x, o, cur)
+    _lib.check(L.bz_ttt_minimax(0, 0, 1, C.byref(mv), C.byref(sc)))
+    assert mv.value == -2  # empty board: the caller draws the opening move (players.py:35-36)
+    _lib.check(L.bz_ttt_minimax(0b000000111, 0b000011000, 1, C.byref(mv), C.byref(sc)))
+    assert (mv.value, sc.value) == (-1, 1)  # finished board: no move, the player has won
+    # unreachable double-line position: X lines are tested first (tic_tac_toe_board.py:31-40), for either player
+    _lib.check(L.bz_ttt_minimax(0b000000111, 0b111000000, 1, C.byref(mv), C.byref(sc)))
+    assert sc.value == 1
+    _lib.check(L.bz_ttt_minimax(0b111000000, 0b000000111, -1, C.byref(mv), C.byref(sc)))
+    assert sc.value == -1
+
+
+def test_ttt_optimal_player_class_never_loses_to_itself_and_matches_memoised_minimax():
+    random.seed(3)
+    for _ in range(5):
+        positions, winner = bz.TicTacToeHeadless(bz.OptimalPlayer(1), bz.OptimalPlayer(-1)).play()
+        assert winner == 0 and len(positions) == 10  # two perfect players draw in 9 plies (as in the reference's CSV)
+    # same decision as the Python MinimaxPlayer of round 1 (same rule, memoised) on random reachable positions
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        t, cur = bz.TicTacToeBoard(), 1
+        for _ in range(int(rng.integers(1, 6))):
+            mv = t.generate_possible_moves()
+            if t.is_game_over()[0] or not mv:
+                break
+            t = t.make_move(*mv[int(rng.integers(len(mv)))], cur)
+            cur = -cur
+        if t.is_game_over()[0]:
+            continue
+        assert bz.OptimalPlayer(cur).get_move(t) == bz.MinimaxPlayer(cur).get_move(t)
