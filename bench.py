@@ -364,11 +364,11 @@ def run_reversi(ctx, args, B, sims, K, W):
     # NS independent pipelines of B/NS games, each on its own HIP stream: the tree step of one
     # overlaps the net kernel of the other and their net launches fill each other's tail wave.
     NS = max(1, args.streams)
-    assert B % NS == 0
-    Bs = B // NS
+    sizes = [B // NS + (1 if i < B % NS else 0) for i in range(NS)]
+    Bs = sizes[0]
     streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(NS)]
-    engs = [SelfPlayEngine("reversi", Bs, sims, "net_" + prec, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
-                           game_id_base=ctx.rank * B + i * Bs, game_id_stride=ctx.world * B, device=ctx.dev,
+    engs = [SelfPlayEngine("reversi", sizes[i], sims, "net_" + prec, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
+                           game_id_base=ctx.rank * B + sum(sizes[:i]), game_id_stride=ctx.world * B, device=ctx.dev,
                            stagger=PLIES_PER_GAME if args.mode == "steady" else 0) for i in range(NS)]
     for e in engs:
         e.reset_games()

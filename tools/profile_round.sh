@@ -1,0 +1,53 @@
+#!/bin/bash
+# Evidence collection for one round, run on the GPU box through gpurun:
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02 [sections]'
+# Raw rocprofv3 output goes to gpurun_out/<tag>prof/; tools/summarize_prof.py then writes the small files
+# that are committed under profiles/.  Counters are collected in their own passes (--pmc with
+# --kernel-trace only), the program sits directly after `--` (no env/bash hop under the profiler).
+TAG=${1:-r02}
+WHAT=${2:-all}
+OUT=gpurun_out/${TAG}prof
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+has() { [ "$WHAT" = all ] || echo "$WHAT" | grep -qw "$1"; }
+run() { echo "== $*" >&2; timeout -k 10 "$@"; echo "   rc=$?" >&2; }
+
+if has stats; then
+  # per-kernel durations of the same command the bench line comes from (agreement check)
+  run 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_s2" -o s2 -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/bench_under_rocprof_streams2.json" 2> "$OUT/stats_s2.err"
+  run 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_s1" -o s1 -- python3 bench.py --steps 6 --warmup 1 --streams 1 --no-cpu-baseline --no-secondary > "$OUT/bench_under_rocprof_streams1.json" 2> "$OUT/stats_s1.err"
+  run 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats_ttt" -o ttt -- python3 bench.py --workload ttt --no-cpu-baseline > "$OUT/bench_ttt_under_rocprof.json" 2> "$OUT/stats_ttt.err"
+  run 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats_env" -o env -- python3 tools/bench_env.py > "$OUT/bench_env.txt" 2> "$OUT/stats_env.err"
+fi
+if has pmc_tower; then
+  run 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d "$OUT/pmc_tower_sq" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_sq.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES -d "$OUT/pmc_tower_inst" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_inst.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_tower_fetch" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_fetch.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_tower_write" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_write.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tower_tcc" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_tcc.txt" 2>&1
+fi
+if has pmc_ttt; then
+  for gw in 2 0; do   # 2 = the TTT-specialised fused search, 0 = the generic fused kernel (the "before")
+    export BZ_TTT_GW=$gw
+    run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d "$OUT/pmc_ttt_sq_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_sq_gw$gw.json" 2> "$OUT/pmc_ttt_sq_gw$gw.err"
+    run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_ttt_tcc_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_tcc_gw$gw.json" 2> "$OUT/pmc_ttt_tcc_gw$gw.err"
+    run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_ttt_fetch_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_fetch_gw$gw.json" 2> "$OUT/pmc_ttt_fetch_gw$gw.err"
+    run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_ttt_write_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_write_gw$gw.json" 2> "$OUT/pmc_ttt_write_gw$gw.err"
+  done
+  unset BZ_TTT_GW
+fi
+if has clock; then
+  # in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz) and per-phase stamps of the fused net kernel
+  run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16.txt" 2>&1
+  FP8=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_fp8.txt" 2>&1
+fi
+if has ab; then
+  # cost of the in-library kernel timers on `value`, and 1 / 2 / 3 pipelines, interleaved on ONE device
+  for i in 1 2; do
+    for v in "--streams 2" "--streams 2 --no-kernel-timers" "--streams 3" "--streams 1"; do
+      tagv=$(echo "$v" | tr -d ' -')
+      run 200 python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-secondary $v > "$OUT/ab_${tagv}_$i.json" 2> /dev/null
+    done
+  done
+fi
+ls -R "$OUT" | head -80 >&2
