@@ -21,6 +21,7 @@
 //  * f32 (parity): per-layer VALU kernels whose every accumulation is the
 //    k-ordered fmaf chain of oracle/bz_oracle.c -> bit-identical to the oracle.
 #include <math.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct bz_net {
     // different streams are ordered through this event (the MFMA paths have no such scratch)
     hipEvent_t f32_done;
     bool f32_used;
+    int tower_mw;  // M-tiles per wave of the bf16 tower (Split<MW>)
 };
 
 namespace {
@@ -218,111 +220,146 @@ __device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
         boff[nt] = c2 * 256 + ((sw ^ h) << 4);
     }
 }
-template <int P>
-__device__ __forceinline__ void load_b(bf16x8 (&b)[P][2], const char* in, const int (&boff)[2], int kc) {
+// Work split of a workgroup's 4 waves over the [128 co] x [4 positions x 64 cells] output of a layer,
+// MW = M-tiles (32 output channels each) per wave:
+//   MW = 1: wave w owns co 32w..32w+31 of all 4 positions  -> per k-step 1 weight fragment (L2) + 8 activation
+//           fragments (LDS) feed 8 MFMAs;
+//   MW = 2: wave w owns co 64(w&1)..+63 of positions 2(w>>1), 2(w>>1)+1 -> 2 weight fragments + 4 activation
+//           fragments feed the same 8 MFMAs: half the LDS read bytes per MFMA, twice the weight bytes (the
+//           second wave of a co half hits L1 for them).
+template <int MW> struct Split {
+    static constexpr int PW = 4 / MW;  // positions per wave
+    static __device__ __forceinline__ int wt0(int w) { return MW == 1 ? w : 2 * (w & 1); }        // first M-tile
+    static __device__ __forceinline__ int pos0(int w) { return MW == 1 ? 0 : 2 * (w >> 1); }     // first position
+};
+
+template <int MW>
+__device__ __forceinline__ void load_b(bf16x8 (&b)[4 / MW][2], const char* in, const int (&boff)[2], int kc) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const char* bp = in + (boff[nt] ^ (kc << 5));
 #pragma unroll
-        for (int p = 0; p < P; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * kTileBytes);
+        for (int p = 0; p < 4 / MW; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * kTileBytes);
     }
 }
-template <int P>
-__device__ __forceinline__ void mfma8(f32x16 (&acc)[P][2], const bf16x8& a, const bf16x8 (&b)[P][2]) {
+template <int MW>
+__device__ __forceinline__ void mfma8(f32x16 (&acc)[MW][4 / MW][2], const bf16x8 (&a)[MW], const bf16x8 (&b)[4 / MW][2]) {
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+    for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[p][nt], acc[p][nt], 0, 0, 0);
+        for (int p = 0; p < 4 / MW; ++p)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[p][nt], acc[mt][p][nt], 0, 0, 0);
 }
 
 // One conv tap = 8 k-steps of 8 MFMAs.  Weight fragments of this tap are in register
-// set S (A0 or A1); the other set is filled for the next tap (one coalesced 1 KB load per
-// k-step, a whole tap ahead).  Activation fragments are double-buffered (b0/b1): the 8
-// ds_read_b128 of k-step k+1 are issued between the MFMAs of k-step k.
-template <int S, int P>
-__device__ __forceinline__ void tap_step(f32x16 (&acc)[P][2], bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap,
-                                         const char* in, int (&boff)[2], int next_tap, int r, int h,
-                                         bf16x8 (&b0)[P][2], bf16x8 (&b1)[P][2]) {
-    bf16x8 (&use)[8] = S ? A1 : A0;
-    bf16x8 (&nxt)[8] = S ? A0 : A1;
+// set S (A0 or A1); the other set is filled for the next tap (coalesced 1 KB loads, a whole
+// tap ahead).  Activation fragments are double-buffered (b0/b1): the ds_read_b128 of k-step
+// k+1 are issued between the MFMAs of k-step k.  `in` already points at the wave's first position.
+template <int S, int MW>
+__device__ __forceinline__ void tap_step(f32x16 (&acc)[MW][4 / MW][2], bf16x8 (&A0)[8][MW], bf16x8 (&A1)[8][MW],
+                                         const uint4*& ap, const char* in, int (&boff)[2], int next_tap, int r, int h,
+                                         bf16x8 (&b0)[4 / MW][2], bf16x8 (&b1)[4 / MW][2]) {
+    bf16x8 (&use)[8][MW] = S ? A1 : A0;
+    bf16x8 (&nxt)[8][MW] = S ? A0 : A1;
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) nxt[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
+    for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256 + mt * 64]);
     ap += 8 * 256;
     int boff_n[2];
     tap_off(next_tap, r, h, boff_n);
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) {
-        load_b<P>(b1, in, boff, 2 * k2 + 1);
-        mfma8<P>(acc, use[2 * k2], b0);
-        if (k2 < 3) load_b<P>(b0, in, boff, 2 * k2 + 2);
-        else load_b<P>(b0, in, boff_n, 0);  // first k-step of the next tap
-        mfma8<P>(acc, use[2 * k2 + 1], b1);
+        load_b<MW>(b1, in, boff, 2 * k2 + 1);
+        mfma8<MW>(acc, use[2 * k2], b0);
+        if (k2 < 3) load_b<MW>(b0, in, boff, 2 * k2 + 2);
+        else load_b<MW>(b0, in, boff_n, 0);  // first k-step of the next tap
+        mfma8<MW>(acc, use[2 * k2 + 1], b1);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        if (MW == 1) {
 #pragma unroll
-        for (int j = 0; j < 2 * P; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            for (int j = 0; j < 8; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                if (j & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 VMEM reads per k-step
+            }
         }
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
     }
     boff[0] = boff_n[0]; boff[1] = boff_n[1];
 }
 
-// +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]: lane (r, h) register 4q+i
-// holds co = 32w + 8q + 4h + i of cell 32nt + r, i.e. 4 consecutive channels = one 8-byte store.
-template <int P>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[P][2], char* out, bool second, const float* __restrict__ bl,
-                                         int w, int r, int h) {
-    f32x4 bq[4];
+// +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]: lane (r, h) register 4q+i of M-tile wt
+// holds co = 32wt + 8q + 4h + i of cell 32nt + r, i.e. 4 consecutive channels = one 8-byte store.
+// `out` already points at the wave's first position.
+template <int MW>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[MW][4 / MW][2], char* out, bool second, const float* __restrict__ bl,
+                                         int wt0, int r, int h) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q);
+    for (int mt = 0; mt < MW; ++mt) {
+        const int wt = wt0 + mt;
+        f32x4 bq[4];
 #pragma unroll
-    for (int p = 0; p < P; ++p)
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * wt + 4 * h + 8 * q);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            int cell = 32 * nt + r;
+        for (int p = 0; p < 4 / MW; ++p)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int off = p * kTileBytes + cell_off(cell, 4 * w + q) + 8 * h;
-                f32x4 v = {acc[p][nt][4 * q], acc[p][nt][4 * q + 1], acc[p][nt][4 * q + 2], acc[p][nt][4 * q + 3]};
-                v = v + bq[q];
-                if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
-                    bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
-                    v = v + __builtin_convertvector(sk, f32x4);
+            for (int nt = 0; nt < 2; ++nt) {
+                int cell = 32 * nt + r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int off = p * kTileBytes + cell_off(cell, 4 * wt + q) + 8 * h;
+                    f32x4 v = {acc[mt][p][nt][4 * q], acc[mt][p][nt][4 * q + 1], acc[mt][p][nt][4 * q + 2], acc[mt][p][nt][4 * q + 3]};
+                    v = v + bq[q];
+                    if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
+                        bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+                        v = v + __builtin_convertvector(sk, f32x4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                    *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-                *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
             }
-        }
+    }
 }
 
 // One conv3x3 layer over the 4 resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
 // S0 = register set that holds tap 0's weight fragments on entry (the other one on exit).
-template <int S0, int P>
+template <int S0, int MW>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
-                                           bf16x8 (&A0)[8], bf16x8 (&A1)[8], const uint4*& ap, int w, int r, int h,
+                                           bf16x8 (&A0)[8][MW], bf16x8 (&A1)[8][MW], const uint4*& ap, int w, int r, int h,
                                            unsigned long long (&tacc)[4]) {
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
-    f32x16 acc[P][2];
+    f32x16 acc[MW][4 / MW][2];
 #pragma unroll
-    for (int p = 0; p < P; ++p) { acc[p][0] = (f32x16)(0.0f); acc[p][1] = (f32x16)(0.0f); }
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int p = 0; p < 4 / MW; ++p) { acc[mt][p][0] = (f32x16)(0.0f); acc[mt][p][1] = (f32x16)(0.0f); }
+    const int wpos = Split<MW>::pos0(w) * kTileBytes;
+    in += wpos; out += wpos;
     int boff[2];
     tap_off(0, r, h, boff);
-    bf16x8 b0[P][2], b1[P][2];
-    load_b<P>(b0, in, boff, 0);
+    bf16x8 b0[4 / MW][2], b1[4 / MW][2];
+    load_b<MW>(b0, in, boff, 0);
 #pragma unroll 1
     for (int t = 0; t < 8; t += 2) {  // taps 0..7; tap 8 uses the same register set as tap 0
-        tap_step<S0, P>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
-        tap_step<1 - S0, P>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
+        tap_step<S0, MW>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
+        tap_step<1 - S0, MW>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
     }
-    tap_step<S0, P>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
+    tap_step<S0, MW>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
     BZ_STAMP(t1);
-    epilogue<P>(acc, out, second, bl, w, r, h);
+    epilogue<MW>(acc, out, second, bl, Split<MW>::wt0(w), r, h);
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);
@@ -373,9 +410,10 @@ __device__ __forceinline__ float wave_sum(float x) {
 // The whole net forward for P positions per workgroup: stem (MFMA, K = 18 padded to 32, fed from
 // the bitboards) -> residual tower (activations resident in LDS) -> heads (conv1x1 by MFMA, the
 // small FCs by one wave per position).  HBM traffic per position: 16 B in, 264 B out.
-template <int P>
+template <int MW>
 __global__ void __launch_bounds__(256, 1)
 k_tower_bf16(TowerArgs T) {
+    constexpr int P = kPosPerWG, PW = 4 / MW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -396,41 +434,51 @@ k_tower_bf16(TowerArgs T) {
         int b = tid / (16 * P), p = (tid >> 4) % P, k = tid & 15;
         *reinterpret_cast<uint4*>(smem + b * buf_bytes<P>() + p * kTileBytes + 64 * 256 + k * 16) = make_uint4(0, 0, 0, 0);
     }
-    // weight-fragment stream of this wave: k-step ks -> wf[(ks*4 + w)*64 + lane], linear over layers
-    const uint4* ap = T.wf + (size_t)w * 64 + lane;
-    bf16x8 A0[8], A1[8];
+    // weight-fragment stream of this wave: k-step ks, M-tile mt -> wf[(ks*4 + mt)*64 + lane], linear over layers
+    const int wt0 = Split<MW>::wt0(w), wp0 = Split<MW>::pos0(w);
+    const uint4* ap = T.wf + (size_t)wt0 * 64 + lane;
+    bf16x8 A0[8][MW], A1[8][MW];
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) A0[kc] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256]);
+    for (int kc = 0; kc < 8; ++kc)
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) A0[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256 + mt * 64]);
     ap += 8 * 256;
 
     // ---- stem: conv3x3 2 -> 128 as a [128 x 32] x [32 x 64] GEMM per position
     {
-        f32x16 acc[P][2];
-        bf16x8 sa[2];
+        f32x16 acc[MW][PW][2];
+        bf16x8 sa[2][MW];
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) sa[kc] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + w) * 64 + lane]);
+        for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            int pos = pos0 + p < T.n ? pos0 + p : T.n - 1;
+            for (int mt = 0; mt < MW; ++mt) sa[kc][mt] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + wt0 + mt) * 64 + lane]);
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            int pos = pos0 + wp0 + p < T.n ? pos0 + wp0 + p : T.n - 1;
             u64 own = T.own[pos], opp = T.opp[pos];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                acc[p][nt] = (f32x16)(0.0f);
+                bf16x8 sf[2];
 #pragma unroll
-                for (int kc = 0; kc < 2; ++kc)
-                    acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc], stem_frag(own, opp, 32 * nt + r, 16 * kc + 8 * h),
-                                                                        acc[p][nt], 0, 0, 0);
+                for (int kc = 0; kc < 2; ++kc) sf[kc] = stem_frag(own, opp, 32 * nt + r, 16 * kc + 8 * h);
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt) {
+                    acc[mt][p][nt] = (f32x16)(0.0f);
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+                        acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc][mt], sf[kc], acc[mt][p][nt], 0, 0, 0);
+                }
             }
         }
-        epilogue<P>(acc, bufX, false, T.stem_b, w, r, h);
+        epilogue<MW>(acc, bufX + wp0 * kTileBytes, false, T.stem_b, wt0, r, h);
     }
     __syncthreads();
 
     // ---- tower: a residual block = conv1 (X -> M) + conv2 (M -> X in place, + skip X)
 #pragma unroll 1
     for (int blk = 0; blk < T.n_layers / 2; ++blk) {
-        conv_layer<0, P>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h, tacc);
-        conv_layer<1, P>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w, r, h, tacc);
+        conv_layer<0, MW>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h, tacc);
+        conv_layer<1, MW>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w, r, h, tacc);
     }
     BZ_STAMP(tk1);
 
@@ -997,9 +1045,14 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     int32_t urc = upload_params(n, p, (hipStream_t)stream);
     if (urc != BZ_OK) { delete n; return urc; }
     if (C == kTC) {
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<kPosPerWG>),
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
-        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
+        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16<1>)"); }
+        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
+        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16<2>)"); }
+        n->tower_mw = 1;
+        if (const char* mw = getenv("BZ_TOWER_MW")) n->tower_mw = atoi(mw) == 2 ? 2 : 1;  // A/B of the wave split (tools/ab_tower_mw.py)
         e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(f8::k_tower_fp8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  f8::kLds);
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_fp8)"); }
@@ -1071,8 +1124,11 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     {
         ProfScope ps(BZ_PROF_TOWER, stream);
         if (fp8) hipLaunchKernelGGL(f8::k_tower_fp8, dim3((cnt + 3) / 4), dim3(256), f8::kLds, s, T);
+        else if (n->tower_mw == 2)
+            hipLaunchKernelGGL(k_tower_bf16<2>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
+                               tower_lds<kPosPerWG>(), s, T);
         else
-            hipLaunchKernelGGL(k_tower_bf16<kPosPerWG>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
+            hipLaunchKernelGGL(k_tower_bf16<1>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
                                tower_lds<kPosPerWG>(), s, T);
     }
     BZ_LAUNCH_CHECK("k_tower_bf16");
