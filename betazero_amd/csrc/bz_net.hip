@@ -53,7 +53,6 @@ struct bz_net {
     // different streams are ordered through this event (the MFMA paths have no such scratch)
     hipEvent_t f32_done;
     bool f32_used;
-    int tower_mw;  // M-tiles per wave of the bf16 tower (Split<MW>)
 };
 
 namespace {
@@ -226,7 +225,9 @@ __device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
 //           fragments (LDS) feed 8 MFMAs;
 //   MW = 2: wave w owns co 64(w&1)..+63 of positions 2(w>>1), 2(w>>1)+1 -> 2 weight fragments + 4 activation
 //           fragments feed the same 8 MFMAs: half the LDS read bytes per MFMA, twice the weight bytes (the
-//           second wave of a co half hits L1 for them).
+//           second wave of a co half hits L1 for them).  Measured in round 2 (profiles/r02_ab_tower_mw.txt,
+//           one process, interleaved, random data): bit-identical outputs, 674.0 vs 678.5 us at 4096
+//           positions (-0.7 %) -- inside the noise of the power-limited clock, so only MW = 1 is instantiated.
 template <int MW> struct Split {
     static constexpr int PW = 4 / MW;  // positions per wave
     static __device__ __forceinline__ int wt0(int w) { return MW == 1 ? w : 2 * (w & 1); }        // first M-tile
@@ -1048,11 +1049,7 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
         hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16<1>)"); }
-        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
-        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16<2>)"); }
-        n->tower_mw = 1;
-        if (const char* mw = getenv("BZ_TOWER_MW")) n->tower_mw = atoi(mw) == 2 ? 2 : 1;  // A/B of the wave split (tools/ab_tower_mw.py)
+
         e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(f8::k_tower_fp8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  f8::kLds);
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_fp8)"); }
@@ -1124,9 +1121,6 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     {
         ProfScope ps(BZ_PROF_TOWER, stream);
         if (fp8) hipLaunchKernelGGL(f8::k_tower_fp8, dim3((cnt + 3) / 4), dim3(256), f8::kLds, s, T);
-        else if (n->tower_mw == 2)
-            hipLaunchKernelGGL(k_tower_bf16<2>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
-                               tower_lds<kPosPerWG>(), s, T);
         else
             hipLaunchKernelGGL(k_tower_bf16<1>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
                                tower_lds<kPosPerWG>(), s, T);
