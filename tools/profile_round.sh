@@ -36,6 +36,11 @@ if has pmc_ttt; then
   done
   unset BZ_TTT_GW
 fi
+if has pmc_env; then
+  run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/pmc_env_sq" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_sq.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_env_fetch" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_fetch.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_env_write" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_write.txt" 2>&1
+fi
 if has clock; then
   # in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz) and per-phase stamps of the fused net kernel
   run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16.txt" 2>&1
