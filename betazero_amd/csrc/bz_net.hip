@@ -182,14 +182,44 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
 }
 
 // ------------------------------------------------------------------ bf16 MFMA tower
-constexpr int kTC = 128;                  // channels
-constexpr int kTileBytes = 65 * 256;      // 64 cells x 256 B + one zero cell
-// positions resident per workgroup: 4 = one workgroup per CU.  (Round 1 measured the alternatives on one
-// device -- 2 positions x 2 workgroups per CU, a tile-major last tap, the 16x16x32 MFMA shape: all within
-// +-1 % because the kernel sits on the chip's power limit, DESIGN.md 5 -- and they were removed.)
-constexpr int kPosPerWG = 4;
-template <int P> constexpr int buf_bytes() { return P * kTileBytes; }
-template <int P> constexpr int tower_lds() { return 2 * P * kTileBytes; }
+constexpr int kTC = 128;                  // channels of the benchmark net (the fp8 tower serves only this width)
+
+// Geometry of the fused bf16 net kernel for C = 64, 128 or 256 channels.  A workgroup of 4 waves keeps P positions
+// resident in LDS (2 buffers x P x TILE = 133 KB for every width: one workgroup per CU) and its 32 accumulator tiles
+// (MT M-tiles of 32 output channels x P positions x 2 cell tiles) are dealt 8 per wave as MW M-tiles x PW positions:
+//   C =  64: P = 8, wave w -> M-tile  w & 1,        positions 4 (w >> 1) .. +3   (MW 1, PW 4)
+//   C = 128: P = 4, wave w -> M-tile  w,            positions 0 .. 3             (MW 1, PW 4)   <- the benchmark net
+//   C = 256: P = 2, wave w -> M-tiles 2w, 2w + 1,   positions 0, 1               (MW 2, PW 2)
+// (Round 1 measured 2 positions x 2 workgroups per CU, a tile-major last tap and the 16x16x32 MFMA shape, round 2 the
+// MW = 2 split at C = 128: all within +-1 % because the kernel sits on the power-limited clock -- DESIGN.md 5.)
+template <int C> struct Tw {
+    static_assert(C == 64 || C == 128 || C == 256, "the MFMA tower is built for 64, 128 or 256 channels");
+    static constexpr int KC = C / 16;                  // k-steps (16 input channels) per conv tap
+    static constexpr int MT = C / 32;                  // M-tiles (32 output channels)
+    static constexpr int CELL = 2 * C;                 // bytes of one board cell (all channels, bf16)
+    static constexpr int ZERO = C == 64 ? 256 : CELL;  // zero region read by the conv halo (128-B cells: one per x parity)
+    static constexpr int TILE = 64 * CELL + ZERO;      // bytes of one position
+    static constexpr int P = 512 / C;                  // positions resident per workgroup
+    static constexpr int BUF = P * TILE;
+    static constexpr int LDS = 2 * BUF;
+    static constexpr int MW = MT >= 8 ? 2 : 1;         // M-tiles per wave
+    static constexpr int PW = 4 / MW;                  // positions per wave
+    static constexpr int NG = MT / MW;                 // wave groups along M
+    static constexpr int KS = KC < 8 ? KC : 8;         // k-steps per weight-prefetch chunk (register set)
+    static constexpr int CPT = KC / KS;                // chunks per tap
+    static constexpr int NCH = 9 * CPT;                // chunks per layer
+    static __device__ __forceinline__ int wt0(int w) { return (w % NG) * MW; }
+    static __device__ __forceinline__ int pos0(int w) { return (w / NG) * PW; }
+    // XOR swizzle of the 16-byte chunk index inside a cell, chosen so that the 16 lanes of every ds_read_b128 lane
+    // group (16 different cells of a 4-row patch, any tap shift) hit 16 distinct 16-byte bank slots: 256-B and
+    // 512-B cells span whole bank rows -> 4 bits from (x, y & 1); 128-B cells share a bank row in pairs (x parity)
+    // -> 3 bits from (x >> 1, y & 1)
+    static __device__ __forceinline__ int sw(int yy, int xx) {
+        return C == 64 ? (((xx & 7) >> 1) | ((yy & 1) << 2)) : ((xx & 7) | ((yy & 1) << 3));
+    }
+    // byte offset of 16-byte chunk k of cell c inside a position tile
+    static __device__ __forceinline__ int cell_off(int c, int k) { return c * CELL + ((k ^ sw(c >> 3, c & 7)) << 4); }
+};
 
 // Diagnostic build only (tools/exp_stamps.sh -> a separate libbz_hip.stamps.so, never the product .so)
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
@@ -201,87 +231,76 @@ __device__ unsigned long long g_dbg[8 * 4096];
 #else
 #define BZ_STAMP(var) do { } while (0)
 #endif
-// byte offset of 16-byte chunk k of cell c inside a position tile (XOR swizzle:
-// the 16 lanes of every ds_read_b128 lane group hit 16 distinct slots)
-__device__ __forceinline__ int cell_off(int c, int k) { return c * 256 + ((k ^ (c & 15)) << 4); }
 
+// LDS byte offsets (inside a position tile) of the B-operand chunk h of k-step 0 for conv tap `tap`, for the lane's
+// two cell tiles; load_b XORs the k-step in.
+template <int C>
 __device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
+    typedef Tw<C> G;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         int cell = 32 * nt + r, yy = (cell >> 3) + dy, xx = (cell & 7) + dx;
         bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
-        int c2 = inb ? yy * 8 + xx : 64;  // out of the board -> the zero cell
-        // swizzle from the UNCLAMPED coordinates: a halo lane then reads the slot of the zero
-        // cell that its virtual cell would occupy, so the 16 lanes of a ds_read_b128 group
-        // still hit 16 distinct slots (no bank conflict between halo and board lanes)
-        int sw = (xx & 7) | ((yy & 1) << 3);
-        boff[nt] = c2 * 256 + ((sw ^ h) << 4);
+        // out of the board -> the zero region.  The swizzle comes from the UNCLAMPED coordinates: a halo lane then
+        // reads the slot of the zero region that its virtual cell would occupy, so the 16 lanes of a ds_read_b128
+        // group still hit 16 distinct slots (no bank conflict between halo and board lanes)
+        int base = inb ? (yy * 8 + xx) * G::CELL : 64 * G::CELL + (C == 64 ? (xx & 1) * 128 : 0);
+        boff[nt] = base + ((G::sw(yy, xx) ^ h) << 4);
     }
 }
-// Work split of a workgroup's 4 waves over the [128 co] x [4 positions x 64 cells] output of a layer,
-// MW = M-tiles (32 output channels each) per wave:
-//   MW = 1: wave w owns co 32w..32w+31 of all 4 positions  -> per k-step 1 weight fragment (L2) + 8 activation
-//           fragments (LDS) feed 8 MFMAs;
-//   MW = 2: wave w owns co 64(w&1)..+63 of positions 2(w>>1), 2(w>>1)+1 -> 2 weight fragments + 4 activation
-//           fragments feed the same 8 MFMAs: half the LDS read bytes per MFMA, twice the weight bytes (the
-//           second wave of a co half hits L1 for them).  Measured in round 2 (profiles/r02_ab_tower_mw.txt,
-//           one process, interleaved, random data): bit-identical outputs, 674.0 vs 678.5 us at 4096
-//           positions (-0.7 %) -- inside the noise of the power-limited clock, so only MW = 1 is instantiated.
-template <int MW> struct Split {
-    static constexpr int PW = 4 / MW;  // positions per wave
-    static __device__ __forceinline__ int wt0(int w) { return MW == 1 ? w : 2 * (w & 1); }        // first M-tile
-    static __device__ __forceinline__ int pos0(int w) { return MW == 1 ? 0 : 2 * (w >> 1); }     // first position
-};
-
-template <int MW>
-__device__ __forceinline__ void load_b(bf16x8 (&b)[4 / MW][2], const char* in, const int (&boff)[2], int kc) {
+template <int C>
+__device__ __forceinline__ void load_b(bf16x8 (&b)[Tw<C>::PW][2], const char* in, const int (&boff)[2], int kc) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const char* bp = in + (boff[nt] ^ (kc << 5));
+        const char* bp = in + (boff[nt] ^ (kc << 5));  // chunk 2 kc + h: the XOR stays inside the cell
 #pragma unroll
-        for (int p = 0; p < 4 / MW; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * kTileBytes);
+        for (int p = 0; p < Tw<C>::PW; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * Tw<C>::TILE);
     }
 }
-template <int MW>
-__device__ __forceinline__ void mfma8(f32x16 (&acc)[MW][4 / MW][2], const bf16x8 (&a)[MW], const bf16x8 (&b)[4 / MW][2]) {
+template <int C>
+__device__ __forceinline__ void mfma8(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], const bf16x8 (&a)[Tw<C>::MW],
+                                      const bf16x8 (&b)[Tw<C>::PW][2]) {
 #pragma unroll
-    for (int mt = 0; mt < MW; ++mt)
+    for (int mt = 0; mt < Tw<C>::MW; ++mt)
 #pragma unroll
-        for (int p = 0; p < 4 / MW; ++p)
+        for (int p = 0; p < Tw<C>::PW; ++p)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[p][nt], acc[mt][p][nt], 0, 0, 0);
 }
 
-// One conv tap = 8 k-steps of 8 MFMAs.  Weight fragments of this tap are in register
-// set S (A0 or A1); the other set is filled for the next tap (coalesced 1 KB loads, a whole
-// tap ahead).  Activation fragments are double-buffered (b0/b1): the ds_read_b128 of k-step
-// k+1 are issued between the MFMAs of k-step k.  `in` already points at the wave's first position.
-template <int S, int MW>
-__device__ __forceinline__ void tap_step(f32x16 (&acc)[MW][4 / MW][2], bf16x8 (&A0)[8][MW], bf16x8 (&A1)[8][MW],
-                                         const uint4*& ap, const char* in, int (&boff)[2], int next_tap, int r, int h,
-                                         bf16x8 (&b0)[4 / MW][2], bf16x8 (&b1)[4 / MW][2]) {
-    bf16x8 (&use)[8][MW] = S ? A1 : A0;
-    bf16x8 (&nxt)[8][MW] = S ? A0 : A1;
+// One weight chunk = KS k-steps of 8 MFMAs (a whole conv tap at C <= 128, half a tap at C = 256).  The chunk's weight
+// fragments are in register set S (A0 or A1); the other set is filled for the next chunk (coalesced 1 KB loads, a
+// whole chunk ahead; the fragment stream is linear over chunks, taps and layers).  Activation fragments are double-
+// buffered (b0/b1): the ds_read_b128 of k-step k+1 are issued between the MFMAs of k-step k.  `in` points at the wave's
+// first position; (boff, kc0) address this chunk, (tap_n, kc0_n) the next one.
+template <int S, int C>
+__device__ __forceinline__ void chunk_step(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], bf16x8 (&A0)[Tw<C>::KS][Tw<C>::MW],
+                                           bf16x8 (&A1)[Tw<C>::KS][Tw<C>::MW], const uint4*& ap, const char* in,
+                                           int (&boff)[2], int kc0, int tap_n, int kc0_n, int r, int h,
+                                           bf16x8 (&b0)[Tw<C>::PW][2], bf16x8 (&b1)[Tw<C>::PW][2]) {
+    typedef Tw<C> G;
+    bf16x8 (&use)[G::KS][G::MW] = S ? A1 : A0;
+    bf16x8 (&nxt)[G::KS][G::MW] = S ? A0 : A1;
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc)
+    for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-        for (int mt = 0; mt < MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256 + mt * 64]);
-    ap += 8 * 256;
+        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+    ap += G::KS * G::MT * 64;
     int boff_n[2];
-    tap_off(next_tap, r, h, boff_n);
+    tap_off<C>(tap_n, r, h, boff_n);
 #pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-        load_b<MW>(b1, in, boff, 2 * k2 + 1);
-        mfma8<MW>(acc, use[2 * k2], b0);
-        if (k2 < 3) load_b<MW>(b0, in, boff, 2 * k2 + 2);
-        else load_b<MW>(b0, in, boff_n, 0);  // first k-step of the next tap
-        mfma8<MW>(acc, use[2 * k2 + 1], b1);
+    for (int k2 = 0; k2 < G::KS / 2; ++k2) {
+        load_b<C>(b1, in, boff, kc0 + 2 * k2 + 1);
+        mfma8<C>(acc, use[2 * k2], b0);
+        if (k2 < G::KS / 2 - 1) load_b<C>(b0, in, boff, kc0 + 2 * k2 + 2);
+        else load_b<C>(b0, in, boff_n, kc0_n);  // first k-step of the next chunk
+        mfma8<C>(acc, use[2 * k2 + 1], b1);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (MW == 1) {
+    for (int i = 0; i < G::KS; ++i) {
+        if (G::MW == 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -302,24 +321,25 @@ __device__ __forceinline__ void tap_step(f32x16 (&acc)[MW][4 / MW][2], bf16x8 (&
 
 // +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]: lane (r, h) register 4q+i of M-tile wt
 // holds co = 32wt + 8q + 4h + i of cell 32nt + r, i.e. 4 consecutive channels = one 8-byte store.
-// `out` already points at the wave's first position.
-template <int MW>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[MW][4 / MW][2], char* out, bool second, const float* __restrict__ bl,
-                                         int wt0, int r, int h) {
+// `out` points at the wave's first position.
+template <int C>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], char* out, bool second,
+                                         const float* __restrict__ bl, int wt0, int r, int h) {
+    typedef Tw<C> G;
 #pragma unroll
-    for (int mt = 0; mt < MW; ++mt) {
+    for (int mt = 0; mt < G::MW; ++mt) {
         const int wt = wt0 + mt;
         f32x4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * wt + 4 * h + 8 * q);
 #pragma unroll
-        for (int p = 0; p < 4 / MW; ++p)
+        for (int p = 0; p < G::PW; ++p)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 int cell = 32 * nt + r;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    int off = p * kTileBytes + cell_off(cell, 4 * wt + q) + 8 * h;
+                    int off = p * G::TILE + G::cell_off(cell, 4 * wt + q) + 8 * h;
                     f32x4 v = {acc[mt][p][nt][4 * q], acc[mt][p][nt][4 * q + 1], acc[mt][p][nt][4 * q + 2], acc[mt][p][nt][4 * q + 3]};
                     v = v + bq[q];
                     if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
@@ -334,33 +354,38 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[MW][4 / MW][2], char* out
     }
 }
 
-// One conv3x3 layer over the 4 resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
-// S0 = register set that holds tap 0's weight fragments on entry (the other one on exit).
-template <int S0, int MW>
+// One conv3x3 layer over the resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
+// S0 = register set that holds chunk 0's weight fragments on entry; on exit it is set S0 ^ (NCH & 1).
+template <int S0, int C>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
-                                           bf16x8 (&A0)[8][MW], bf16x8 (&A1)[8][MW], const uint4*& ap, int w, int r, int h,
-                                           unsigned long long (&tacc)[4]) {
+                                           bf16x8 (&A0)[Tw<C>::KS][Tw<C>::MW], bf16x8 (&A1)[Tw<C>::KS][Tw<C>::MW],
+                                           const uint4*& ap, int w, int r, int h, unsigned long long (&tacc)[4]) {
+    typedef Tw<C> G;
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
-    f32x16 acc[MW][4 / MW][2];
+    f32x16 acc[G::MW][G::PW][2];
 #pragma unroll
-    for (int mt = 0; mt < MW; ++mt)
+    for (int mt = 0; mt < G::MW; ++mt)
 #pragma unroll
-        for (int p = 0; p < 4 / MW; ++p) { acc[mt][p][0] = (f32x16)(0.0f); acc[mt][p][1] = (f32x16)(0.0f); }
-    const int wpos = Split<MW>::pos0(w) * kTileBytes;
+        for (int p = 0; p < G::PW; ++p) { acc[mt][p][0] = (f32x16)(0.0f); acc[mt][p][1] = (f32x16)(0.0f); }
+    const int wpos = G::pos0(w) * G::TILE;
     in += wpos; out += wpos;
     int boff[2];
-    tap_off(0, r, h, boff);
-    bf16x8 b0[4 / MW][2], b1[4 / MW][2];
-    load_b<MW>(b0, in, boff, 0);
+    tap_off<C>(0, r, h, boff);
+    bf16x8 b0[G::PW][2], b1[G::PW][2];
+    load_b<C>(b0, in, boff, 0);
+    // chunk c covers tap c / CPT, k-steps (c % CPT) * KS ..; the chunk after the last one is a harmless re-read
+    auto tap_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return c / G::CPT; };
+    auto kc0_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return (c % G::CPT) * G::KS; };
 #pragma unroll 1
-    for (int t = 0; t < 8; t += 2) {  // taps 0..7; tap 8 uses the same register set as tap 0
-        tap_step<S0, MW>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
-        tap_step<1 - S0, MW>(acc, A0, A1, ap, in, boff, t + 2 < 9 ? t + 2 : 8, r, h, b0, b1);
+    for (int c = 0; c + 1 < G::NCH; c += 2) {
+        chunk_step<S0, C>(acc, A0, A1, ap, in, boff, kc0_of(c), tap_of(c + 1), kc0_of(c + 1), r, h, b0, b1);
+        chunk_step<1 - S0, C>(acc, A0, A1, ap, in, boff, kc0_of(c + 1), tap_of(c + 2), kc0_of(c + 2), r, h, b0, b1);
     }
-    tap_step<S0, MW>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);  // next_tap: harmless re-read
+    if (G::NCH & 1)
+        chunk_step<S0, C>(acc, A0, A1, ap, in, boff, kc0_of(G::NCH - 1), tap_of(G::NCH), kc0_of(G::NCH), r, h, b0, b1);
     BZ_STAMP(t1);
-    epilogue<MW>(acc, out, second, bl, Split<MW>::wt0(w), r, h);
+    epilogue<C>(acc, out, second, bl, G::wt0(w), r, h);
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);
@@ -411,10 +436,11 @@ __device__ __forceinline__ float wave_sum(float x) {
 // The whole net forward for P positions per workgroup: stem (MFMA, K = 18 padded to 32, fed from
 // the bitboards) -> residual tower (activations resident in LDS) -> heads (conv1x1 by MFMA, the
 // small FCs by one wave per position).  HBM traffic per position: 16 B in, 264 B out.
-template <int MW>
+template <int C>
 __global__ void __launch_bounds__(256, 1)
 k_tower_bf16(TowerArgs T) {
-    constexpr int P = kPosPerWG, PW = 4 / MW;
+    typedef Tw<C> G;
+    constexpr int P = G::P, PW = G::PW, MW = G::MW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -427,32 +453,32 @@ k_tower_bf16(TowerArgs T) {
     tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
     char* bufX = smem;
-    char* bufM = smem + buf_bytes<P>();
+    char* bufM = smem + G::BUF;
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- zero cells (conv halo) of both buffers
-    if (tid < 32 * P) {
-        int b = tid / (16 * P), p = (tid >> 4) % P, k = tid & 15;
-        *reinterpret_cast<uint4*>(smem + b * buf_bytes<P>() + p * kTileBytes + 64 * 256 + k * 16) = make_uint4(0, 0, 0, 0);
+    // ---- zero regions (conv halo) of both buffers
+    for (int i = tid; i < 2 * P * (G::ZERO / 16); i += 256) {
+        int k = i % (G::ZERO / 16), p = (i / (G::ZERO / 16)) % P, b = i / (P * (G::ZERO / 16));
+        *reinterpret_cast<uint4*>(smem + b * G::BUF + p * G::TILE + 64 * G::CELL + k * 16) = make_uint4(0, 0, 0, 0);
     }
-    // weight-fragment stream of this wave: k-step ks, M-tile mt -> wf[(ks*4 + mt)*64 + lane], linear over layers
-    const int wt0 = Split<MW>::wt0(w), wp0 = Split<MW>::pos0(w);
+    // weight-fragment stream of this wave: k-step ks, M-tile mt -> wf[(ks * MT + mt) * 64 + lane], linear over layers
+    const int wt0 = G::wt0(w), wp0 = G::pos0(w);
     const uint4* ap = T.wf + (size_t)wt0 * 64 + lane;
-    bf16x8 A0[8][MW], A1[8][MW];
+    bf16x8 A0[G::KS][MW], A1[G::KS][MW];
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc)
+    for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-        for (int mt = 0; mt < MW; ++mt) A0[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)kc * 256 + mt * 64]);
-    ap += 8 * 256;
+        for (int mt = 0; mt < MW; ++mt) A0[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+    ap += G::KS * G::MT * 64;
 
-    // ---- stem: conv3x3 2 -> 128 as a [128 x 32] x [32 x 64] GEMM per position
+    // ---- stem: conv3x3 2 -> C as a [C x 32] x [32 x 64] GEMM per position
     {
         f32x16 acc[MW][PW][2];
         bf16x8 sa[2][MW];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-            for (int mt = 0; mt < MW; ++mt) sa[kc][mt] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + wt0 + mt) * 64 + lane]);
+            for (int mt = 0; mt < MW; ++mt) sa[kc][mt] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * G::MT + wt0 + mt) * 64 + lane]);
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             int pos = pos0 + wp0 + p < T.n ? pos0 + wp0 + p : T.n - 1;
@@ -471,32 +497,32 @@ k_tower_bf16(TowerArgs T) {
                 }
             }
         }
-        epilogue<MW>(acc, bufX + wp0 * kTileBytes, false, T.stem_b, wt0, r, h);
+        epilogue<C>(acc, bufX + wp0 * G::TILE, false, T.stem_b, wt0, r, h);
     }
     __syncthreads();
 
     // ---- tower: a residual block = conv1 (X -> M) + conv2 (M -> X in place, + skip X)
 #pragma unroll 1
     for (int blk = 0; blk < T.n_layers / 2; ++blk) {
-        conv_layer<0, MW>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * kTC, A0, A1, ap, w, r, h, tacc);
-        conv_layer<1, MW>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * kTC, A0, A1, ap, w, r, h, tacc);
+        conv_layer<0, C>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * C, A0, A1, ap, w, r, h, tacc);
+        conv_layer<(G::NCH & 1), C>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * C, A0, A1, ap, w, r, h, tacc);
     }
     BZ_STAMP(tk1);
 
-    // ---- heads: wave p serves position p.  conv1x1 (policy 2 ch + value 1 ch) by MFMA against
-    // the resident tile, then the FCs in fp32 with the position's 192 features staged in LDS.
-    if (w < P && pos0 + w < T.n) {
-        const int p = w, pos = pos0 + w;
-        float* S = reinterpret_cast<float*>(bufM + p * 1024);  // [pf 128 | vf 64]
-        const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
+    // ---- heads: wave w serves positions w, w + 4, ...  conv1x1 (policy 2 ch + value 1 ch) by MFMA against
+    // the resident tile, then the FCs in fp32 with the position's 192 features staged in LDS (M is dead now).
+    float* S = reinterpret_cast<float*>(bufM + w * 1024);  // [pf 128 | vf 64], one scratch per wave
+    const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
+    for (int p = w; p < P && pos0 + p < T.n; p += 4) {
+        const int pos = pos0 + p;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             f32x16 acc = (f32x16)(0.0f);
             const int cell = 32 * nt + r;
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
+            for (int kc = 0; kc < G::KC; ++kc) {
                 bf16x8 a = __builtin_bit_cast(bf16x8, T.head_wf[kc * 64 + lane]);
-                bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * kTileBytes + cell_off(cell, 2 * kc + h));
+                bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * G::TILE + G::cell_off(cell, 2 * kc + h));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             }
             if (h == 0) {  // rows 0..2 of D live in registers 0..2 of lanes 0..31
@@ -529,6 +555,7 @@ k_tower_bf16(TowerArgs T) {
         }
         vh = wave_sum(vh);
         if (lane == 0) T.value[pos] = tanhf_spec(vh + T.v2_b[0]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // the scratch is reused for the wave's next position
     }
 #ifdef BZ_EXP_STAMPS
     unsigned long long tk2; BZ_STAMP(tk2);
@@ -838,8 +865,10 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     int64_t L = 2 * NB, mbp = (mb + 7) & ~7;
     o.stem_w = k.take(18LL * C * 4); o.stem_b = k.take(C * 4LL);
     o.conv_w = k.take(L * 9 * C * C * 4); o.conv_b = k.take(L * C * 4);
-    o.conv_wf = k.take(C == kTC ? (L * 9 + 1) * 8LL * 4 * 64 * 16 : 0);
-    o.stem_wf = k.take(2 * 4 * 64 * 16); o.head_wf = k.take(8 * 64 * 16);
+    const bool mfma = C == 64 || C == 128 || C == 256;  // widths the fused bf16 MFMA kernel is built for
+    const int64_t KC = C / 16, MT = C / 32;             // k-steps per tap, M-tiles (1-KB fragments: [kc][mt][64 lanes][8])
+    o.conv_wf = k.take(mfma ? (L * 9 + 1) * KC * MT * 1024 : 0);
+    o.stem_wf = k.take(mfma ? 2 * MT * 1024 : 0); o.head_wf = k.take(mfma ? KC * 1024 : 0);
     o.conv_wf8 = k.take(C == kTC ? (L * 9 + 1) * 2LL * 4 * 2 * 64 * 16 : 0); o.head_wf8 = k.take(2 * 2 * 64 * 16);
     o.dq8 = k.take((L + 1) * 128 * 4); o.head_dq8 = k.take(16); o.ones = k.take(128 * 4);
     o.pol_w = k.take(2LL * C * 4); o.pol_b = k.take(8); o.polfc_wT = k.take(128 * 65 * 4); o.polfc_b = k.take(65 * 4);
@@ -850,7 +879,7 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     return o;
 }
 bool shape_ok(int C, int NB, int VH, int mb) {
-    return (C == 32 || C == 64 || C == 128) && NB >= 0 && NB <= 64 && VH >= 1 && VH <= 64 && mb >= 1;
+    return (C == 32 || C == 64 || C == 128 || C == 256) && NB >= 0 && NB <= 64 && VH >= 1 && VH <= 64 && mb >= 1;
 }
 uint16_t f2bf(float f) {
     u32 u;
@@ -900,15 +929,17 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
     for (int co = 0; co < C; ++co)
         for (int ci = 0; ci < 2; ++ci)
             for (int t = 0; t < 9; ++t) F(o.stem_w)[(t * 2 + ci) * C + co] = q[(co * 2 + ci) * 9 + t];
-    if (C == kTC) {  // stem as GEMM fragments: A[co][k], k = 2*tap + plane, zero for k >= 18
+    const bool mfma = C == 64 || C == 128 || C == 256;
+    const int KC = C / 16, MT = C / 32;
+    if (mfma) {  // stem as GEMM fragments: A[co][k], k = 2*tap + plane, zero for k >= 18
         uint16_t* sf = reinterpret_cast<uint16_t*>(img.data() + o.stem_wf);
         for (int kc = 0; kc < 2; ++kc)
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
                 for (int ln = 0; ln < 64; ++ln)
                     for (int j = 0; j < 8; ++j) {
                         int co = 32 * mt + (ln & 31), k = 16 * kc + 8 * (ln >> 5) + j;
                         float v = k < 18 ? q[(co * 2 + (k & 1)) * 9 + (k >> 1)] : 0.0f;
-                        sf[(((size_t)kc * 4 + mt) * 64 + ln) * 8 + j] = f2bf(v);
+                        sf[(((size_t)kc * MT + mt) * 64 + ln) * 8 + j] = f2bf(v);
                     }
     }
     q += (size_t)C * 18;
@@ -922,9 +953,9 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                 for (int t = 0; t < 9; ++t) {
                     float v = q[((size_t)co * C + ci) * 9 + t];
                     wl[((size_t)t * C + ci) * C + co] = v;
-                    if (C == kTC) {  // fragment-major: [l][t][kc][mt][lane = 32h + r][j]
+                    if (mfma) {  // fragment-major: [l][t][kc][mt][lane = 32h + r][j]
                         int kc = ci >> 4, hh = (ci >> 3) & 1, j = ci & 7, mt = co >> 5, rr = co & 31;
-                        size_t f = ((((size_t)l * 9 + t) * 8 + kc) * 4 + mt) * 64 + (hh * 32 + rr);
+                        size_t f = ((((size_t)l * 9 + t) * KC + kc) * MT + mt) * 64 + (hh * 32 + rr);
                         wf[f * 8 + j] = f2bf(v);
                     }
                 }
@@ -971,15 +1002,17 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
     for (int i = 0; i < VH; ++i) F(o.v2_w)[i] = q[i];
     q += VH;
     F(o.v2_b)[0] = q[0];
-    if (C == kTC) {  // head conv1x1 fragments: rows 0,1 = policy channels, row 2 = value channel
+    if (mfma) {  // head conv1x1 fragments: rows 0,1 = policy channels, row 2 = value channel
         uint16_t* hf = reinterpret_cast<uint16_t*>(img.data() + o.head_wf);
-        for (int kc = 0; kc < 8; ++kc)
+        for (int kc = 0; kc < KC; ++kc)
             for (int ln = 0; ln < 64; ++ln)
                 for (int j = 0; j < 8; ++j) {
                     int row = ln & 31, k = 16 * kc + 8 * (ln >> 5) + j;
                     float v = row < 2 ? F(o.pol_w)[row * C + k] : (row == 2 ? F(o.val_w)[k] : 0.0f);
                     hf[((size_t)kc * 64 + ln) * 8 + j] = f2bf(v);
                 }
+    }
+    if (C == kTC) {
         uint8_t* h8 = reinterpret_cast<uint8_t*>(img.data() + o.head_wf8);
         float hs[3];
         for (int row = 0; row < 3; ++row) {
@@ -1027,7 +1060,7 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->C = C; n->NB = NB; n->VH = VH; n->max_batch = max_batch;
     n->stem_w = at<float>(ws, o.stem_w); n->stem_b = at<float>(ws, o.stem_b);
     n->conv_w = at<float>(ws, o.conv_w); n->conv_b = at<float>(ws, o.conv_b);
-    n->conv_wf = C == kTC ? at<__bf16>(ws, o.conv_wf) : nullptr;
+    n->conv_wf = (C == 64 || C == 128 || C == 256) ? at<__bf16>(ws, o.conv_wf) : nullptr;
     n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
     n->conv_wf8 = C == kTC ? at<uint8_t>(ws, o.conv_wf8) : nullptr; n->head_wf8 = at<uint8_t>(ws, o.head_wf8);
     n->dq8 = at<float>(ws, o.dq8); n->head_dq8 = at<float>(ws, o.head_dq8); n->ones = at<float>(ws, o.ones);
@@ -1045,12 +1078,24 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     }
     int32_t urc = upload_params(n, p, (hipStream_t)stream);
     if (urc != BZ_OK) { delete n; return urc; }
+    {
+        hipError_t e3 = hipSuccess;
+        if (C == 64) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<64>::LDS);
+        if (C == 128) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<128>::LDS);
+        if (C == 256) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<256>::LDS);
+        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
+        // the f32 parity kernels stage a whole position in LDS: above 64 KB at C = 256
+        if (C == 256) {
+            e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_heads<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((64 * (C + 1) + 128 + 64 + 64) * sizeof(float)));
+            if (e3 == hipSuccess)
+                e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_f32), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(64 * C * sizeof(float)));
+            if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(f32 parity kernels)"); }
+        }
+    }
     if (C == kTC) {
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, tower_lds<kPosPerWG>());
-        if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16<1>)"); }
-
-        e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(f8::k_tower_fp8), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(f8::k_tower_fp8), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  f8::kLds);
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_fp8)"); }
     }
@@ -1121,9 +1166,12 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     {
         ProfScope ps(BZ_PROF_TOWER, stream);
         if (fp8) hipLaunchKernelGGL(f8::k_tower_fp8, dim3((cnt + 3) / 4), dim3(256), f8::kLds, s, T);
+        else if (n->C == 64)
+            hipLaunchKernelGGL(k_tower_bf16<64>, dim3((cnt + Tw<64>::P - 1) / Tw<64>::P), dim3(256), Tw<64>::LDS, s, T);
+        else if (n->C == 256)
+            hipLaunchKernelGGL(k_tower_bf16<256>, dim3((cnt + Tw<256>::P - 1) / Tw<256>::P), dim3(256), Tw<256>::LDS, s, T);
         else
-            hipLaunchKernelGGL(k_tower_bf16<1>, dim3((cnt + kPosPerWG - 1) / kPosPerWG), dim3(256),
-                               tower_lds<kPosPerWG>(), s, T);
+            hipLaunchKernelGGL(k_tower_bf16<128>, dim3((cnt + Tw<128>::P - 1) / Tw<128>::P), dim3(256), Tw<128>::LDS, s, T);
     }
     BZ_LAUNCH_CHECK("k_tower_bf16");
     return BZ_OK;
@@ -1132,7 +1180,9 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
 int32_t bz_net_forward_dev(bz_net* n, int bf16 /* 0 f32, 1 bf16, 2 fp8 */, const uint64_t* own, const uint64_t* opp, int32_t max_n,
                            const uint32_t* n_dev, float* logits, float* value, void* stream) {
     BZ_REQUIRE(n && own && opp && logits && value, "bz_net_forward: null pointer");
-    BZ_REQUIRE(!bf16 || n->C == kTC, "bz_net_forward_bf16: the MFMA tower is built for C == 128");
+    BZ_REQUIRE(bf16 != 1 || n->C == 64 || n->C == 128 || n->C == 256,
+               "bz_net_forward_bf16: the MFMA tower is built for 64, 128 or 256 channels");
+    BZ_REQUIRE(bf16 != 2 || n->C == kTC, "bz_net_forward_fp8: the fp8 tower is built for C == 128");
     BZ_REQUIRE(max_n >= 0 && max_n <= n->max_batch, "bz_net_forward: batch exceeds max_batch");
     if (max_n == 0) return BZ_OK;
     return bf16 ? forward_bf16(n, own, opp, max_n, n_dev, logits, value, stream, bf16 == 2)

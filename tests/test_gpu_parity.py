@@ -270,7 +270,7 @@ def _positions(n, seed=1):
     return rows[idx, 4].copy(), rows[idx, 5].copy()
 
 
-@pytest.mark.parametrize("C,NB", [(32, 2), (64, 1), (128, 6)])
+@pytest.mark.parametrize("C,NB", [(32, 2), (64, 1), (128, 6), (256, 1)])
 def test_net_f32_bitexact_vs_oracle(C, NB):
     from betazero_amd.net import DeviceNet
     m = _net(C, NB)
@@ -971,3 +971,32 @@ def test_ttt_specialised_fused_search_equals_generic_kernel_and_oracle(gw, monke
             assert np.array_equal(a[0][g], n) and np.array_equal(a[1][g], w.view(np.uint32))
     monkeypatch.setenv("BZ_TTT_GW", gw)
     _check_selfplay("ttt", 96, 40, "hash", 4, 0, 7, base=300)
+
+
+@pytest.mark.parametrize("C,NB", [(64, 3), (256, 2)])
+def test_net_bf16_mfma_other_widths_vs_oracle_bf16_emulation(C, NB):
+    """the fused bf16 MFMA kernel at 64 channels (8 positions per workgroup, 128-byte cells, 3-bit swizzle) and at
+    256 channels (2 positions per workgroup, two M-tiles per wave, half-tap weight chunks) vs the oracle's bf16
+    emulation, at ragged batch sizes (not multiples of the workgroup's positions), plus self-play with the net in the
+    loop (legal, terminates) and equality of every row with the same position evaluated in another batch."""
+    from betazero_amd.net import DeviceNet
+    m = _net(C, NB, seed=7, bf16=True)
+    on = orc.Net(C, NB, 64, m.flat_params())
+    dn = DeviceNet.from_module(m, 64)
+    worst = (0.0, 0.0)
+    for n in (1, 7, 37):
+        own, opp = _positions(n, seed=20 + n)
+        lg, v = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)
+        olg, ov = on.forward(own, opp, bf16=True)
+        el, ev = np.abs(lg.cpu().numpy() - olg).max(), np.abs(v.cpu().numpy() - ov).max()
+        worst = (max(worst[0], el), max(worst[1], ev))
+        assert el < 2e-3 and ev < 1e-3, (C, n, el, ev)
+    print(f"bf16 MFMA net C={C}: worst |dlogit| {worst[0]:.2e} |dv| {worst[1]:.2e}; logit std {olg.std():.3f}")
+    own, opp = _positions(37, seed=57)
+    a = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)[0].cpu().numpy()
+    b = dn.forward(_dev_u64(own[5:30]), _dev_u64(opp[5:30]), bf16=True)[0].cpu().numpy()
+    assert np.array_equal(a[5:30].view(np.uint32), b.view(np.uint32))  # rows do not depend on their neighbours
+    eng = _engine("reversi", 12, 6, "net_bf16", net=dn, temp_moves=8, openings=1)
+    eng.run_iteration()
+    ex = eng.examples()
+    assert (eng.winners()[1][0] > 20).all() and _legal_per_oracle(ex.own, ex.opp, ex.act)
