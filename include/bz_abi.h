@@ -168,7 +168,8 @@ int32_t bz_net_destroy(bz_net* net);
 int32_t bz_net_update(bz_net* net, const float* params_host, void* stream);
 /* own/opp: device u64[n]; logits: device f32[n][65]; value: device f32[n].
  * _f32: exact parity mode (k-ordered fmaf chains == oracle bit for bit).
- * _bf16: MFMA path (bf16 activations/weights, fp32 accumulate); needs C==128. */
+ * _bf16: MFMA path (bf16 activations/weights, fp32 accumulate); C = 64, 128 or 256
+ *        (C = 32 nets run on the _f32 path only). */
 int32_t bz_net_forward_f32(bz_net* net, const uint64_t* own, const uint64_t* opp, int32_t n,
                            float* logits, float* value, void* stream);
 int32_t bz_net_forward_bf16(bz_net* net, const uint64_t* own, const uint64_t* opp, int32_t n,
