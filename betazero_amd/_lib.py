@@ -14,6 +14,7 @@ GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3
 EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_EXTERNAL, EVAL_NET_FP8 = range(6)
 ST_RUNNING, ST_TERMINAL, ST_ILLEGAL, ST_MUST_PASS = range(4)
 PASS_ACTION = 64
+ENGINE_REUSE_SUBTREE = 1
 PROF_SLOTS = ("tower", "stem", "heads", "select", "expand_backup", "search_fused", "play", "env_step")
 COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",
                  "n_child_written", "n_env_steps", "n_net_leaves")
@@ -24,7 +25,8 @@ u64, u32, i32, i64, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_void_
 class EngineCfg(C.Structure):
     _fields_ = [("game", i32), ("n_games", i32), ("sims", i32), ("eval_kind", i32), ("c_puct", C.c_float),
                 ("temp_moves", i32), ("openings", i32), ("rounds", i32), ("t_max", i32), ("stagger", i32),
-                ("seed", u64), ("game_id_base", u64), ("game_id_stride", u64)]
+                ("seed", u64), ("game_id_base", u64), ("game_id_stride", u64),
+                ("flags", u32), ("dirichlet_alpha", C.c_float), ("dirichlet_eps", C.c_float), ("reserved", u32)]
 
 
 class EngineLayout(C.Structure):

@@ -81,4 +81,77 @@ BZ_HD u64 rng_draw(u64 seed, u64 game_id, u64 ply) {
     return mix64(h ^ (ply * 0xBF58476D1CE4E5B9ULL + 0x94D049BB133111EBULL));
 }
 
+// ---- Dirichlet root noise (opt-in).  Everything is float32 with one rounding per
+// operation in the written order, so the C oracle, the numpy twin and the kernels agree bit for bit.
+BZ_HD u32 f_to_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    u32 b;
+    __builtin_memcpy(&b, &f, 4);
+    return b;
+#endif
+}
+// ln(x) for normal x > 0 (Cephes logf: m in [sqrt(1/2), sqrt(2)), degree-8 polynomial in m - 1)
+BZ_HD float logf_spec(float x) {
+    u32 b = f_to_bits(x);
+    int e = (int)(b >> 23) - 127;
+    float m = f_from_bits((b & 0x007FFFFFu) | 0x3F800000u);  // [1, 2)
+    if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
+    float z = m - 1.0f;
+    float p = 7.0376836292e-2f;
+    p = p * z + -1.1514610310e-1f;
+    p = p * z + 1.1676998740e-1f;
+    p = p * z + -1.2420140846e-1f;
+    p = p * z + 1.4249322787e-1f;
+    p = p * z + -1.6668057665e-1f;
+    p = p * z + 2.0000714765e-1f;
+    p = p * z + -2.4999993993e-1f;
+    p = p * z + 3.3333331174e-1f;
+    float zz = z * z;
+    float y = z * zz;
+    y = y * p;
+    float fe = (float)e;
+    float t = fe * -2.12194440e-4f;
+    y = y + t;
+    t = 0.5f * zz;
+    y = y - t;
+    float r = z + y;
+    t = fe * 0.693359375f;
+    r = r + t;
+    return r;
+}
+// uniform in (0, 1): 23 random bits + 1/2, exact in float32
+BZ_HD float u01_spec(u64 bits) { return ((float)(u32)(bits >> 41) + 0.5f) * (1.0f / 8388608.0f); }
+BZ_HD u64 rng_noise(u64 seed, u64 game_id, u64 ply, u64 idx) {
+    u64 h = rng_draw(seed ^ 0xD1B54A32D192ED03ULL, game_id, ply);
+    return mix64(h + idx * 0x9E3779B97F4A7C15ULL);
+}
+// Gamma(alpha, 1) variate for 0 < alpha <= 1 and root edge number `edge` (ascending action order).
+// alpha = 1: exponential.  alpha < 1: Johnk's generator -- X = U^(1/alpha), Y = V^(1/(1-alpha)), accept when
+// X + Y <= 1, return E X / (X + Y) with E exponential -- at most 16 attempts (acceptance > 0.78 per attempt;
+// the 16th attempt's values are used regardless).
+BZ_HD float gamma_spec(float alpha, u64 seed, u64 game_id, u64 ply, int edge) {
+    const u64 base = (u64)edge * 64ULL;
+    if (!(alpha < 1.0f)) return -logf_spec(u01_spec(rng_noise(seed, game_id, ply, base)));
+    const float ia = fdiv(1.0f, alpha), ib = fdiv(1.0f, 1.0f - alpha);
+    float x = 0.0f, s = 0.0f;
+    u64 k = base;
+    for (int t = 0; t < 16; ++t) {
+        k = base + 3ULL * (u64)t;
+        float lu = logf_spec(u01_spec(rng_noise(seed, game_id, ply, k)));
+        float lv = logf_spec(u01_spec(rng_noise(seed, game_id, ply, k + 1)));
+        lu = lu * ia;
+        lv = lv * ib;
+        x = expf_spec(lu < 0.0f ? lu : 0.0f);
+        float y = expf_spec(lv < 0.0f ? lv : 0.0f);
+        s = x + y;
+        if (s <= 1.0f) break;
+    }
+    if (!(s > 0.0f)) return 0.0f;
+    float e = -logf_spec(u01_spec(rng_noise(seed, game_id, ply, k + 2)));
+    float g = e * x;
+    return fdiv(g, s);
+}
+
 }  // namespace bz

@@ -46,7 +46,7 @@ enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, E
 struct EngineDev {
     int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd, stagger;
     int compact;  // net evaluators: leaves needing evaluation are packed (c_own/c_opp/logits/value by slot)
-    float c_puct;
+    float c_puct, dir_alpha, dir_eps;  // dir_eps > 0: Dirichlet noise on the root priors
     u64 seed, id_base, id_stride;
     Node* nodes; Edge* edges;
     u64 *g_own, *g_opp; int8_t* g_to_move; uint8_t* g_state; int32_t *g_moves, *g_nex, *g_round, *g_passes;
@@ -250,9 +250,31 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
 #pragma unroll
         for (int k = 0; k < kCH; ++k)
             for (int j = 0; j < kGW && kGW * k + j < n; ++j) s = s + __shfl(ex[k], j, kGW);
+        float pr[kCH];
+#pragma unroll
+        for (int k = 0; k < kCH; ++k) pr[k] = a[k] >= 0 ? fdiv(ex[k], s) : 0.0f;
+        if (leaf == 0 && E.dir_eps > 0.0f) {  // root of a search: P' = (1 - eps) P + eps eta, eta ~ Dirichlet(alpha)
+            const u64 gid = E.id_base + (u64)E.g_round[g] * E.id_stride + (u64)g, ply = (u64)E.g_moves[g];
+            float gm[kCH];
+#pragma unroll
+            for (int k = 0; k < kCH; ++k) gm[k] = a[k] >= 0 ? gamma_spec(E.dir_alpha, E.seed, gid, ply, sub + kGW * k) : 0.0f;
+            float gs = 0.0f;  // ascending-edge serial sum, as for the softmax
+#pragma unroll
+            for (int k = 0; k < kCH; ++k)
+                for (int j = 0; j < kGW && kGW * k + j < n; ++j) gs = gs + __shfl(gm[k], j, kGW);
+            if (gs > 0.0f) {
+                const float keep = 1.0f - E.dir_eps;
+#pragma unroll
+                for (int k = 0; k < kCH; ++k) {
+                    float t1 = keep * pr[k];
+                    float t2 = E.dir_eps * fdiv(gm[k], gs);
+                    pr[k] = t1 + t2;
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kCH; ++k)
-            if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = fdiv(ex[k], s); e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
+            if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = pr[k]; e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
     }
     if (sub == 0) {
         if (kHeader) *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);  // edge0, info: one 8-byte store
@@ -788,7 +810,8 @@ struct Offsets {
 bool cfg_ok(const bz_engine_cfg* c) {
     return c && c->game >= BZ_GAME_TTT && c->game <= BZ_GAME_REVERSI4 && c->n_games > 0 && c->sims >= 1 &&
            c->sims < (1 << 20) && c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_NET_FP8 && c->rounds >= 1 &&
-           c->t_max >= 1;
+           c->t_max >= 1 && c->dirichlet_eps >= 0.0f && c->dirichlet_eps <= 1.0f &&
+           (c->dirichlet_eps == 0.0f || (c->dirichlet_alpha > 0.0f && c->dirichlet_alpha <= 1.0f));
 }
 
 Offsets carve(const bz_engine_cfg& c) {
@@ -867,7 +890,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
     d.stagger = cfg->stagger;
-    d.c_puct = cfg->c_puct; d.seed = cfg->seed; d.id_base = cfg->game_id_base; d.id_stride = cfg->game_id_stride;
+    d.c_puct = cfg->c_puct; d.dir_alpha = cfg->dirichlet_alpha; d.dir_eps = cfg->dirichlet_eps; d.seed = cfg->seed; d.id_base = cfg->game_id_base; d.id_stride = cfg->game_id_stride;
     d.nodes = at<Node>(ws, o.nodes); d.edges = at<Edge>(ws, o.edges);
     d.g_own = at<u64>(ws, o.g_own); d.g_opp = at<u64>(ws, o.g_opp); d.g_to_move = at<int8_t>(ws, o.g_to_move);
     d.g_state = at<uint8_t>(ws, o.g_state); d.g_moves = at<int32_t>(ws, o.g_moves); d.g_nex = at<int32_t>(ws, o.g_nex);

@@ -54,14 +54,16 @@ class Examples:
 
 class SelfPlayEngine:
     def __init__(self, game, n_games, sims, evaluator="uniform", net=None, c_puct=1.5, temp_moves=0, openings=0,
-                 seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0", stagger=0):
+                 seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0", stagger=0,
+                 dirichlet_alpha=0.0, dirichlet_eps=0.0, reuse_subtree=False):
         _lib.require_gpu()
         L = _lib.lib()
         self.game = _GAMES[game]
         self.device = torch.device(device)
         t_max = 9 if self.game == GAME_TTT else 64
         self.cfg = EngineCfg(self.game, n_games, sims, _EVALS[evaluator], c_puct, temp_moves, openings, rounds, t_max,
-                             stagger, seed, game_id_base, n_games if game_id_stride is None else game_id_stride)
+                             stagger, seed, game_id_base, n_games if game_id_stride is None else game_id_stride,
+                             _lib.ENGINE_REUSE_SUBTREE if reuse_subtree else 0, dirichlet_alpha, dirichlet_eps, 0)
         nbytes = L.bz_engine_workspace_bytes(C.byref(self.cfg))
         if nbytes < 0:
             raise RuntimeError(_lib.last_error())

@@ -203,7 +203,16 @@ typedef struct bz_engine_cfg {
     uint64_t seed;
     uint64_t game_id_base;   /* global id of slot 0, round 0 (= rank * n_games) */
     uint64_t game_id_stride; /* id distance between rounds (= world_size * n_games) */
+    /* opt-in search features (all zero = the BASELINE configurations) */
+    uint32_t flags;          /* BZ_ENGINE_* bits */
+    float dirichlet_alpha;   /* 0 < alpha <= 1 when dirichlet_eps > 0 */
+    float dirichlet_eps;     /* > 0: root priors P' = (1 - eps) P + eps Dirichlet(alpha), a fresh draw per
+                              * search keyed by (seed, game id, moves made) -- DESIGN.md 3.9 */
+    uint32_t reserved;
 } bz_engine_cfg;
+/* keep the chosen child's subtree as the next search's tree; searches then go through the
+ * step kernels for every evaluator */
+#define BZ_ENGINE_REUSE_SUBTREE 1u
 
 /* offsets (bytes, from the workspace base) of the caller-visible arrays */
 typedef struct bz_engine_layout {

@@ -25,7 +25,8 @@ def build():
 
 class SpCfg(C.Structure):
     _fields_ = [("game", C.c_int), ("sims", C.c_int), ("eval_kind", C.c_int), ("temp_moves", C.c_int),
-                ("openings", C.c_int), ("max_moves", C.c_int), ("c_puct", C.c_float), ("seed", C.c_uint64)]
+                ("openings", C.c_int), ("max_moves", C.c_int), ("c_puct", C.c_float), ("seed", C.c_uint64),
+                ("flags", C.c_uint), ("dir_alpha", C.c_float), ("dir_eps", C.c_float)]
 
 
 _lib = None
@@ -70,6 +71,13 @@ def lib():
         L.orc_net_destroy.argtypes = [C.c_void_p]
         L.orc_net_forward.restype = None
         L.orc_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, i32, i32, C.c_void_p, C.c_void_p]
+        L.orc_logf.restype = C.c_float
+        L.orc_logf.argtypes = [C.c_float]
+        L.orc_gamma.restype = C.c_float
+        L.orc_gamma.argtypes = [C.c_float, u64, u64, u64, i32]
+        L.orc_mcts_search_noise.restype = i32
+        L.orc_mcts_search_noise.argtypes = [i32, u64, u64, i32, i32, i32, C.c_float, C.c_void_p, C.c_float, C.c_float, u64, u64,
+                                            u64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_mcts_search.restype = i32
         L.orc_mcts_search.argtypes = [i32, u64, u64, i32, i32, i32, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
@@ -168,24 +176,34 @@ class Net:
 
 
 # ---------------------------------------------------------------- mcts / self-play
-def mcts_search(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None):
+def logf(x):
+    return np.float32(lib().orc_logf(float(np.float32(x))))
+
+
+def gamma(alpha, seed, gid, ply, edge):
+    return np.float32(lib().orc_gamma(float(np.float32(alpha)), seed, gid, ply, edge))
+
+
+def mcts_search(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None, dir_alpha=0.0, dir_eps=0.0, seed=0,
+                gid=0, ply=0):
     na = 9 if game == GAME_TTT else 65
     N = np.zeros(na, np.uint32)
     W = np.zeros(na, np.float32)
     P = np.zeros(na, np.float32)
     cnt = np.zeros(8, np.uint64)
-    rc = lib().orc_mcts_search(game, own, opp, to_move, sims, eval_kind, c_puct, net.h if net else None,
-                               N.ctypes.data, W.ctypes.data, P.ctypes.data, cnt.ctypes.data)
+    rc = lib().orc_mcts_search_noise(game, own, opp, to_move, sims, eval_kind, c_puct, net.h if net else None,
+                                     dir_alpha, dir_eps, seed, gid, ply,
+                                     N.ctypes.data, W.ctypes.data, P.ctypes.data, cnt.ctypes.data)
     if rc:
         raise ValueError("terminal root")
     return N, W, P, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
 
 
 def selfplay_game(game, gid, sims, eval_kind, temp_moves=0, openings=0, seed=0, c_puct=1.5, net=None,
-                  max_moves=0):
+                  max_moves=0, dir_alpha=0.0, dir_eps=0.0, reuse=False):
     na = 9 if game == GAME_TTT else 65
     tmax = 16 if game == GAME_TTT else 64
-    cfg = SpCfg(game, sims, eval_kind, temp_moves, openings, max_moves, c_puct, seed)
+    cfg = SpCfg(game, sims, eval_kind, temp_moves, openings, max_moves, c_puct, seed, 1 if reuse else 0, dir_alpha, dir_eps)
     own = np.zeros(tmax, np.uint64)
     opp = np.zeros(tmax, np.uint64)
     pi = np.zeros((tmax, na), np.float32)

@@ -81,6 +81,66 @@ def expf_spec(x):
     return f32(p * scale)
 
 
+def logf_spec(x):
+    """ln for normal x > 0 (Cephes logf), single float32 roundings, no fma."""
+    b = int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+    e = (b >> 23) - 127
+    m = np.array([(b & 0x007FFFFF) | 0x3F800000], dtype=np.uint32).view(np.float32)[0]
+    if m > f32(1.41421356):
+        m = m * f32(0.5)
+        e = e + 1
+    z = m - f32(1.0)
+    p = f32(7.0376836292e-2)
+    for c in (-1.1514610310e-1, 1.1676998740e-1, -1.2420140846e-1, 1.4249322787e-1, -1.6668057665e-1,
+              2.0000714765e-1, -2.4999993993e-1, 3.3333331174e-1):
+        p = p * z + f32(c)
+    zz = z * z
+    y = z * zz
+    y = y * p
+    fe = f32(e)
+    t = fe * f32(-2.12194440e-4)
+    y = y + t
+    t = f32(0.5) * zz
+    y = y - t
+    r = z + y
+    t = fe * f32(0.693359375)
+    r = r + t
+    return f32(r)
+
+
+def u01_spec(bits):
+    return (f32(bits >> 41) + f32(0.5)) * f32(1.0 / 8388608.0)
+
+
+def rng_noise(seed, gid, ply, idx):
+    h = rng_draw(seed ^ 0xD1B54A32D192ED03, gid, ply)
+    return mix64((h + idx * 0x9E3779B97F4A7C15) & M64)
+
+
+def gamma_spec(alpha, seed, gid, ply, edge):
+    """Gamma(alpha, 1), 0 < alpha <= 1: exponential at alpha = 1, Johnk's generator below (<= 16 attempts)"""
+    alpha = f32(alpha)
+    base = edge * 64
+    if not (alpha < f32(1.0)):
+        return f32(-logf_spec(u01_spec(rng_noise(seed, gid, ply, base))))
+    ia, ib = f32(1.0) / alpha, f32(1.0) / (f32(1.0) - alpha)
+    x, s, k = f32(0.0), f32(0.0), base
+    for t in range(16):
+        k = base + 3 * t
+        lu = logf_spec(u01_spec(rng_noise(seed, gid, ply, k))) * ia
+        lv = logf_spec(u01_spec(rng_noise(seed, gid, ply, k + 1))) * ib
+        x = expf_spec(lu if lu < f32(0.0) else f32(0.0))
+        y = expf_spec(lv if lv < f32(0.0) else f32(0.0))
+        s = x + y
+        if s <= f32(1.0):
+            break
+    if not (s > f32(0.0)):
+        return f32(0.0)
+    e = -logf_spec(u01_spec(rng_noise(seed, gid, ply, k + 2)))
+    g = e * x
+    return f32(g / s)
+
+
 def eval_hash(own, opp, na):
     h = mix64(((own * 0x9E3779B97F4A7C15) & M64) ^ mix64((opp + 0x632BE59BD9B4E019) & M64))
     logits = []
@@ -97,9 +157,12 @@ class Twin:
     every env transition goes through generate_possible_moves / make_move / is_game_over / get_score
     of the board classes handed in."""
 
-    def __init__(self, game, eval_kind, c_puct=1.5, boards=None):
+    def __init__(self, game, eval_kind, c_puct=1.5, boards=None, dir_alpha=0.0, dir_eps=0.0, reuse=False):
         # boards = (ReversiBoard, TicTacToeBoard) classes with the reference's Game API
         self.ReversiBoard, self.TicTacToeBoard = boards
+        # opt-in search features (DESIGN.md 3.9, 3.10); the noise key (seed, gid, ply) is set per search
+        self.dir_alpha, self.dir_eps, self.reuse = f32(dir_alpha), f32(dir_eps), reuse
+        self.noise_key = (0, 0, 0)
         self.size = {"reversi6": 6, "reversi4": 4}.get(game, 8)
         self.label = game
         game = "reversi" if game.startswith("reversi") else game
@@ -151,6 +214,23 @@ class Twin:
         node["edges"] = [{"a": a, "N": 0, "W": f32(0), "P": f32(e / s), "child": None} for a, e in zip(mv, es)]
         return v
 
+    def root_noise(self, root):
+        """P' = (1 - eps) P + eps eta, eta ~ Dirichlet(alpha) over the root's edges in ascending action order"""
+        if not (self.dir_eps > 0) or root["edges"] is None:
+            return
+        seed, gid, ply = self.noise_key
+        g = [gamma_spec(self.dir_alpha, seed, gid, ply, i) for i in range(len(root["edges"]))]
+        gs = f32(0.0)
+        for x in g:
+            gs = gs + x
+        if not (gs > 0):
+            return
+        keep = f32(1.0) - self.dir_eps
+        for e, x in zip(root["edges"], g):
+            t1 = keep * e["P"]
+            t2 = self.dir_eps * f32(x / gs)
+            e["P"] = f32(t1 + t2)
+
     def new_node(self, b, p):
         over, w = self.terminal(b)
         return {"b": b, "p": p, "term": over, "tv": w * p, "edges": None}
@@ -190,6 +270,7 @@ class Twin:
         root = self.new_node(b, p)
         assert not root["term"]
         self.expand(root)
+        self.root_noise(root)
         for _ in range(sims):
             self.simulate(root)
         return root
@@ -208,6 +289,7 @@ class Twin:
                 p, made = -p, made + 1
         ex = []
         while True:
+            self.noise_key = (seed, gid, made)
             root = self.search(b, p, sims)
             sumN = sum(e["N"] for e in root["edges"])
             pi = [f32(0.0)] * self.na

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_struct_sizes_match_header():
-    assert C.sizeof(_lib.EngineCfg) == 64
+    assert C.sizeof(_lib.EngineCfg) == 80
     assert C.sizeof(_lib.EngineLayout) == 21 * 8 + 8 + 3 * 8
 
 
@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     assert b"size" in L.bz_last_error()
     assert L.bz_reversi_apply(0, 0, 8, 0, 0, C.byref(out), C.byref(out), None) == _lib.BZ_EILLEGAL_MOVE
     assert L.bz_engine_workspace_bytes(None) == -1
-    cfg = _lib.EngineCfg(1, 4, 8, 0, 1.5, 0, 0, 1, 64, 0, 0, 0, 4)
+    cfg = _lib.EngineCfg(1, 4, 8, 0, 1.5, 0, 0, 1, 64, 0, 0, 0, 4, 0, 0.0, 0.0, 0)
     assert L.bz_engine_workspace_bytes(C.byref(cfg)) > 0
 
 

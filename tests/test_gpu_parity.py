@@ -1000,3 +1000,51 @@ def test_net_bf16_mfma_other_widths_vs_oracle_bf16_emulation(C, NB):
     eng.run_iteration()
     ex = eng.examples()
     assert (eng.winners()[1][0] > 20).all() and _legal_per_oracle(ex.own, ex.opp, ex.act)
+
+
+# ---------------------------------------------------------------- opt-in search features
+@pytest.mark.parametrize("gw", ["2", "4", "0"])
+def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw, monkeypatch):
+    """Dirichlet noise on the root priors (float32 log / Gamma sampler spec'd to the bit): root
+    N / W / P of noisy searches and complete noisy self-play games equal the oracle's, for the TTT-specialised
+    fused kernel (2, 4 lanes), the generic fused kernel (BZ_TTT_GW=0, and Reversi) and the step kernels (f32 net)."""
+    from betazero_amd.net import DeviceNet
+    monkeypatch.setenv("BZ_TTT_GW", gw)
+    d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
+    live = d["pos"][d["pos"][:, 4] == 0]
+    sel = live[np.random.default_rng(1).choice(len(live), 120, replace=False)]
+    tm = np.where(sel[:, 2] == 1, 1, -1).astype(np.int8)
+    own = np.where(tm == 1, sel[:, 0], sel[:, 1]).astype(np.uint64)
+    opp = np.where(tm == 1, sel[:, 1], sel[:, 0]).astype(np.uint64)
+    for alpha in (0.3, 1.0):
+        eng = _engine("ttt", len(sel), 60, "hash", seed=5, game_id_base=1000, dirichlet_alpha=alpha, dirichlet_eps=0.25)
+        eng.set_roots(own, opp, tm)
+        eng.search()
+        N, W, P = eng.root_stats()
+        eng.status()
+        for g in range(len(sel)):
+            n, w, p, _ = orc.mcts_search(orc.GAME_TTT, int(own[g]), int(opp[g]), int(tm[g]), 60, orc.EVAL_HASH,
+                                         dir_alpha=alpha, dir_eps=0.25, seed=5, gid=1000 + g, ply=0)
+            assert np.array_equal(N[g], n) and np.array_equal(W[g].view(np.uint32), w.view(np.uint32)), (alpha, g)
+            assert np.array_equal(P[g].view(np.uint32), p.view(np.uint32)), (alpha, g)
+    if gw != "4":
+        return
+    # Reversi: generic fused kernel (hash) and the step kernels (f32 net), whole games with a fresh draw per move
+    for ev, oev, net, onet, n_games, sims in (("hash", orc.EVAL_HASH, None, None, 24, 40),):
+        eng = _engine("reversi", n_games, sims, ev, temp_moves=6, openings=1, seed=3, game_id_base=50,
+                      dirichlet_alpha=0.5, dirichlet_eps=0.25)
+        eng.run_iteration()
+        ex = eng.examples()
+        for g in range(n_games):
+            r = orc.selfplay_game(orc.GAME_REVERSI, 50 + g, sims, oev, 6, 1, 3, dir_alpha=0.5, dir_eps=0.25)
+            m = ex.game == 50 + g
+            assert np.array_equal(ex.act[m], r["act"]) and np.array_equal(ex.pi[m].view(np.uint32), r["pi"].view(np.uint32))
+    m = _net(32, 2, seed=4)
+    dn, on = DeviceNet.from_module(m, 8), orc.Net(32, 2, 64, m.flat_params())
+    eng = _engine("reversi", 6, 10, "net_f32", net=dn, temp_moves=4, openings=1, seed=8, dirichlet_alpha=0.3, dirichlet_eps=0.5)
+    eng.run_iteration()
+    ex = eng.examples()
+    for g in range(6):
+        r = orc.selfplay_game(orc.GAME_REVERSI, g, 10, orc.EVAL_NET_F32, 4, 1, 8, net=on, dir_alpha=0.3, dir_eps=0.5)
+        mk = ex.game == g
+        assert np.array_equal(ex.act[mk], r["act"]) and np.array_equal(ex.pi[mk].view(np.uint32), r["pi"].view(np.uint32))
