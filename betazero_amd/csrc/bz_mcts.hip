@@ -35,7 +35,9 @@ struct __attribute__((aligned(16))) Edge { u32 N; float W; float P; u32 ca; };
 static_assert(sizeof(Node) == 32 && sizeof(Edge) == 16, "layout");
 
 constexpr u32 kTerm = 1u << 8;
-enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2 };
+// leaf_kind: NONE = slot idle; EVAL = the leaf awaits (logits, value); TERMINAL = backup of a terminal value;
+// READY = nothing to expand or back up, select at once (a root whose subtree was kept from the previous move)
+enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2, LEAF_READY = 3 };
 enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDED, CNT_CHILD_WRITTEN,
        CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_N };
 // NEVAL[2]: packed-leaf counters, double-buffered by simulation parity (the tree step that
@@ -46,6 +48,8 @@ enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, E
 struct EngineDev {
     int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd, stagger;
     int compact;  // net evaluators: leaves needing evaluation are packed (c_own/c_opp/logits/value by slot)
+    int reuse;    // BZ_ENGINE_REUSE_SUBTREE: two tree arenas; nodes/edges = this move's, *_alt = the previous move's
+    Node* nodes_alt; Edge* edges_alt; u32 *g_reuse, *g_root_base;
     float c_puct, dir_alpha, dir_eps;  // dir_eps > 0: Dirichlet noise on the root priors
     u64 seed, id_base, id_stride;
     Node* nodes; Edge* edges;
@@ -136,7 +140,8 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u
     constexpr int kGW = G::GW;
     Node* nodes = E.nodes + (size_t)g * E.ncap;
     Edge* edges = E.edges + (size_t)g * E.ecap;
-    u32 node = 0, sumN = sim_idx;  // sum of the root's child visits == simulations done so far
+    // sum of the root's child visits == simulations done so far (+ the visits a kept subtree came with)
+    u32 node = 0, sumN = sim_idx + (E.reuse ? E.g_root_base[g] : 0u);
     int depth = 0;
     const bool lead = sub == 0;
     if (lead) c.v[CNT_SIMS]++;
@@ -348,6 +353,7 @@ __device__ __forceinline__ void dev_start_game(const EngineDev& E, int g, int ro
     }
     E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm;
     E.g_moves[g] = made; E.g_nex[g] = 0; E.g_round[g] = round; E.g_passes[g] = 0; E.g_state[g] = 0;
+    if (E.reuse) { E.g_reuse[g] = 0; E.g_root_base[g] = 0; }
 }
 
 template <class G>
@@ -386,8 +392,56 @@ __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, 
     if (g >= E.B) return;
     E.g_own[g] = own[g]; E.g_opp[g] = opp[g]; E.g_to_move[g] = tm[g];
     E.g_state[g] = tm[g] == 0 ? 1 : 0;  // to_move 0 = slot not in use (the arena searches a subset of its games)
+    if (E.reuse) { E.g_reuse[g] = 0; E.g_root_base[g] = 0; }
     E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
     if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0; }
+}
+
+// Subtree reuse: copy the subtree below node `src_root` of the previous move's arena to the front of
+// this move's arena, breadth first (Cheney): node 0 = the new root, a node's edges stay one contiguous block in
+// ascending action order, child ids and edge0 are rewritten.  One lane per game; a few hundred nodes per move.
+// Then, if enabled, a fresh Dirichlet draw on the root's stored priors (the noise of 3.9 for a root that is
+// not expanded anew).
+template <class G>
+__device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_root) {
+    const Node* sn = E.nodes_alt + (size_t)g * E.ncap;
+    const Edge* se = E.edges_alt + (size_t)g * E.ecap;
+    Node* dn = E.nodes + (size_t)g * E.ncap;
+    Edge* de = E.edges + (size_t)g * E.ecap;
+    u32 n_dst = 1, e_dst = 0;
+    dn[0] = sn[src_root];
+    for (u32 i = 0; i < n_dst; ++i) {
+        Node nd = dn[i];  // edge0 still points into the source arena
+        if (nd.info & kTerm) continue;
+        const u32 n = nd.info & 0xFFu, s0 = nd.edge0;
+        for (u32 j = 0; j < n; ++j) {
+            Edge e = se[s0 + j];
+            const u32 child = e.ca & 0xFFFFFFu;
+            if (child) {
+                const u32 id = n_dst++;
+                dn[id] = sn[child];
+                e.ca = id | (e.ca & 0xFF000000u);
+            }
+            de[e_dst + j] = e;
+        }
+        dn[i].edge0 = e_dst;
+        e_dst += n;
+    }
+    E.n_nodes[g] = n_dst; E.n_edges[g] = e_dst;
+    if (E.dir_eps > 0.0f) {
+        const u64 gid = E.id_base + (u64)E.g_round[g] * E.id_stride + (u64)g, ply = (u64)E.g_moves[g];
+        const int n = (int)(dn[0].info & 0xFFu);
+        float gs = 0.0f;
+        for (int i = 0; i < n; ++i) gs = gs + gamma_spec(E.dir_alpha, E.seed, gid, ply, i);
+        if (gs > 0.0f) {
+            const float keep = 1.0f - E.dir_eps;
+            for (int i = 0; i < n; ++i) {
+                float t1 = keep * de[i].P;
+                float t2 = E.dir_eps * fdiv(gamma_spec(E.dir_alpha, E.seed, gid, ply, i), gs);
+                de[i].P = t1 + t2;
+            }
+        }
+    }
 }
 
 template <class G>
@@ -395,9 +449,15 @@ __global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     uint8_t kind = LEAF_NONE;
-    if (E.g_state[g] == 0 && dev_root_init<G>(E, g)) {
+    const u32 keep = (E.reuse && E.g_state[g] == 0) ? E.g_reuse[g] : 0u;
+    if (keep) {
+        dev_reroot<G>(E, g, keep);
+        kind = LEAF_READY;
+        E.leaf_node[g] = 0; E.depth[g] = 0;
+    } else if (E.g_state[g] == 0 && dev_root_init<G>(E, g)) {
         kind = LEAF_EVAL;
         E.n_nodes[g] = 1; E.n_edges[g] = 0; E.leaf_node[g] = 0; E.depth[g] = 0;
+        if (E.reuse) E.g_root_base[g] = 0;
     }
     E.leaf_own[g] = E.g_own[g]; E.leaf_opp[g] = E.g_opp[g];
     E.leaf_kind[g] = kind;
@@ -431,7 +491,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
     if (g < E.B) {
         int kind = E.leaf_kind[g];
         const bool active = E.g_state[g] == 0 && kind != LEAF_NONE;
-        if (do_expand && kind != LEAF_NONE) {
+        if (do_expand && (kind == LEAF_EVAL || kind == LEAF_TERMINAL)) {
             u32 leaf = E.leaf_node[g];
             const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
             const u64 nlegal = nd->legal; const u32 ninfo = nd->info;
@@ -750,6 +810,7 @@ __global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
         }
     }
     int a = (int)(ed[pick].ca >> 24);
+    u32 keep_node = ed[pick].ca & 0xFFFFFFu, keep_N = ed[pick].N;  // subtree reuse: the chosen child and its visits
     E.ex_own[row] = root.own; E.ex_opp[row] = root.opp; E.ex_mover[row] = (int8_t)tm; E.ex_act[row] = (uint8_t)a;
     nex++;
     u64 own, opp;
@@ -768,6 +829,16 @@ __global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
     } else if (lg == 0) {  // the next mover cannot move: flip the side again
         u64 t = own; own = opp; opp = t; tm = -tm;
         E.g_passes[g]++;
+        if (E.reuse && keep_node) {  // the kept root lies behind the child's only edge, the pass
+            const Node cn = E.nodes[(size_t)g * E.ncap + keep_node];
+            const Edge pe = E.edges[(size_t)g * E.ecap + cn.edge0];
+            keep_node = pe.ca & 0xFFFFFFu; keep_N = pe.N;
+        }
+    }
+    if (E.reuse) {  // keep the subtree iff it exists and the next search cannot outgrow the arena
+        const bool ok = keep_node != 0 && keep_N + (u32)E.sims + 2u <= (u32)E.ncap;
+        E.g_reuse[g] = ok ? keep_node : 0u;
+        E.g_root_base[g] = ok ? keep_N - 1u : 0u;
     }
     E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm; E.g_moves[g] = made; E.g_nex[g] = nex;
 }
@@ -800,7 +871,7 @@ struct Carver {
 };
 
 struct Offsets {
-    int64_t nodes, edges, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
+    int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_root_base, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
         path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
         ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, total;
     int n_cnt_slots;
@@ -819,12 +890,16 @@ Offsets carve(const bz_engine_cfg& c) {
     bool ttt = c.game == BZ_GAME_TTT;
     o.na = ttt ? TicTacToe::NA : Reversi::NA;
     o.maxd = ttt ? TicTacToe::MAXD : Reversi::MAXD;
-    o.ncap = c.sims + 2;
-    o.ecap = (c.sims + 2) * (ttt ? TicTacToe::MAXCH : Reversi::MAXCH);
+    const bool reuse = (c.flags & BZ_ENGINE_REUSE_SUBTREE) != 0;
+    o.ncap = (reuse ? 4 : 1) * (c.sims + 2);  // a kept subtree + sims new nodes must fit
+    o.ecap = o.ncap * (ttt ? TicTacToe::MAXCH : Reversi::MAXCH);
     int64_t B = c.n_games, R = c.rounds, T = c.t_max;
     Carver k;
     o.nodes = k.take(B * o.ncap * (int64_t)sizeof(Node));
     o.edges = k.take(B * o.ecap * (int64_t)sizeof(Edge));
+    o.nodes_alt = k.take(reuse ? B * o.ncap * (int64_t)sizeof(Node) : 0);
+    o.edges_alt = k.take(reuse ? B * o.ecap * (int64_t)sizeof(Edge) : 0);
+    o.g_reuse = k.take(reuse ? B * 4 : 0); o.g_root_base = k.take(reuse ? B * 4 : 0);
     o.g_own = k.take(B * 8); o.g_opp = k.take(B * 8); o.g_to_move = k.take(B); o.g_state = k.take(B);
     o.g_moves = k.take(B * 4); o.g_nex = k.take(B * 4); o.g_round = k.take(B * 4); o.g_passes = k.take(B * 4);
     o.n_nodes = k.take(B * 4); o.n_edges = k.take(B * 4);
@@ -892,6 +967,9 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.stagger = cfg->stagger;
     d.c_puct = cfg->c_puct; d.dir_alpha = cfg->dirichlet_alpha; d.dir_eps = cfg->dirichlet_eps; d.seed = cfg->seed; d.id_base = cfg->game_id_base; d.id_stride = cfg->game_id_stride;
     d.nodes = at<Node>(ws, o.nodes); d.edges = at<Edge>(ws, o.edges);
+    d.reuse = (cfg->flags & BZ_ENGINE_REUSE_SUBTREE) ? 1 : 0;
+    d.nodes_alt = at<Node>(ws, o.nodes_alt); d.edges_alt = at<Edge>(ws, o.edges_alt);
+    d.g_reuse = at<u32>(ws, o.g_reuse); d.g_root_base = at<u32>(ws, o.g_root_base);
     d.g_own = at<u64>(ws, o.g_own); d.g_opp = at<u64>(ws, o.g_opp); d.g_to_move = at<int8_t>(ws, o.g_to_move);
     d.g_state = at<uint8_t>(ws, o.g_state); d.g_moves = at<int32_t>(ws, o.g_moves); d.g_nex = at<int32_t>(ws, o.g_nex);
     d.g_round = at<int32_t>(ws, o.g_round); d.g_passes = at<int32_t>(ws, o.g_passes);
@@ -1015,7 +1093,7 @@ BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {
 BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     int ek = e->cfg.eval_kind;
-    if (ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) {
+    if ((ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) && !e->dev.reuse) {
         ProfScope ps(BZ_PROF_SEARCH_FUSED, stream);
         if (e->cfg.game == BZ_GAME_TTT && e->cfg.sims <= kTttFusedMaxSims && e->ttt_gw > 0) {
             const dim3 grid = grid_groups(e->dev.B, e->ttt_gw);
@@ -1049,8 +1127,14 @@ BZ_EXPORT int32_t bz_engine_root_stats(bz_engine* e, void* stream) {
 
 BZ_EXPORT int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream) {
     BZ_REQUIRE(e, "null engine");
-    ProfScope ps(BZ_PROF_PLAY, stream);
-    BZ_DISPATCH(e, k_play, stream, e->dev, (int)restart);
+    {
+        ProfScope ps(BZ_PROF_PLAY, stream);
+        BZ_DISPATCH(e, k_play, stream, e->dev, (int)restart);
+    }
+    if (e->dev.reuse) {  // the tree just searched becomes the source of the next root_begin's subtree copy
+        Node* tn = e->dev.nodes; e->dev.nodes = e->dev.nodes_alt; e->dev.nodes_alt = tn;
+        Edge* te = e->dev.edges; e->dev.edges = e->dev.edges_alt; e->dev.edges_alt = te;
+    }
     return BZ_OK;
 }
 

@@ -288,9 +288,16 @@ class Twin:
                 b = self.play(b, p, a)
                 p, made = -p, made + 1
         ex = []
+        kept = None  # subtree reuse: the node that becomes the next root, statistics and all
         while True:
             self.noise_key = (seed, gid, made)
-            root = self.search(b, p, sims)
+            if kept is not None:
+                root = kept
+                self.root_noise(root)
+                for _ in range(sims):
+                    self.simulate(root)
+            else:
+                root = self.search(b, p, sims)
             sumN = sum(e["N"] for e in root["edges"])
             pi = [f32(0.0)] * self.na
             for e in root["edges"]:
@@ -315,5 +322,10 @@ class Twin:
             over, w = self.terminal(b)
             if over:
                 return ex, w, passes
+            keep_node, keep_N = pick["child"], pick["N"]
             if not self.moves(b, p):
                 p, passes = -p, passes + 1
+                if keep_node is not None:  # the kept root lies behind the child's only edge, the pass
+                    pe = keep_node["edges"][0]
+                    keep_node, keep_N = pe["child"], pe["N"]
+            kept = keep_node if (self.reuse and keep_node is not None and keep_N + sims + 2 <= 4 * (sims + 2)) else None

@@ -1048,3 +1048,58 @@ def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw, monkeyp
         r = orc.selfplay_game(orc.GAME_REVERSI, g, 10, orc.EVAL_NET_F32, 4, 1, 8, net=on, dir_alpha=0.3, dir_eps=0.5)
         mk = ex.game == g
         assert np.array_equal(ex.act[mk], r["act"]) and np.array_equal(ex.pi[mk].view(np.uint32), r["pi"].view(np.uint32))
+
+
+def test_subtree_reuse_selfplay_vs_oracle_bitexact():
+    """subtree reuse: the chosen child's subtree is copied to the front of the other arena and searched on
+    (`sims` new simulations on top of the retained statistics), through passes, with the arena-capacity rule, with and
+    without root noise, over two rounds of games.  Whole games and the work counters equal the oracle's."""
+    from betazero_amd.net import DeviceNet
+    cases = (("ttt", orc.GAME_TTT, 48, 30, 3, 0, 0.0, 0.0), ("reversi", orc.GAME_REVERSI, 32, 40, 6, 1, 0.0, 0.0),
+             ("reversi6", orc.GAME_REVERSI6, 24, 25, 4, 0, 0.5, 0.25), ("reversi4", orc.GAME_REVERSI4, 24, 40, 4, 0, 0.3, 0.25))
+    total_pass = 0
+    for game, og, n, sims, tmv, openings, alpha, eps in cases:
+        eng = _engine(game, n, sims, "hash", temp_moves=tmv, openings=openings, seed=7, game_id_base=10,
+                      dirichlet_alpha=alpha, dirichlet_eps=eps, reuse_subtree=True)
+        eng.reset_counters()
+        eng.run_iteration()
+        ex = eng.examples()
+        winners, lens = eng.winners()
+        cnt = eng.counters()
+        exp = {k: 0 for k in cnt}
+        for g in range(n):
+            r = orc.selfplay_game(og, 10 + g, sims, orc.EVAL_HASH, tmv, openings, 7, reuse=True, dir_alpha=alpha, dir_eps=eps)
+            m = ex.game == 10 + g
+            assert lens[0, g] == len(r["own"]) and winners[0, g] == r["winner"], (game, g)
+            assert np.array_equal(ex.act[m], r["act"]) and np.array_equal(ex.own[m], r["own"]), (game, g)
+            assert np.array_equal(ex.pi[m].view(np.uint32), r["pi"].view(np.uint32)), (game, g)
+            for k in exp:
+                exp[k] += r["counters"][k]
+            total_pass += r["passes"]
+        for k in ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded", "n_child_written", "n_env_steps"):
+            assert cnt[k] == exp[k], (game, k, cnt[k], exp[k])
+    assert total_pass > 0
+    # f32 net in the loop (step kernels with packed leaves), two rounds with restart
+    m = _net(32, 2, seed=4)
+    dn, on = DeviceNet.from_module(m, 8), orc.Net(32, 2, 64, m.flat_params())
+    eng = _engine("reversi", 6, 12, "net_f32", net=dn, temp_moves=8, openings=1, seed=2, reuse_subtree=True)
+    eng.run_iteration()
+    ex = eng.examples()
+    for g in range(6):
+        r = orc.selfplay_game(orc.GAME_REVERSI, g, 12, orc.EVAL_NET_F32, 8, 1, 2, net=on, reuse=True)
+        mk = ex.game == g
+        assert np.array_equal(ex.act[mk], r["act"]) and np.array_equal(ex.pi[mk].view(np.uint32), r["pi"].view(np.uint32))
+    # bf16 MFMA net, 800 simulations on top of the kept subtree: capacity rule, legality, visit sums >= sims
+    dn = DeviceNet.from_module(_net(128, 6, bf16=True), 64)
+    eng = _engine("reversi", 64, 200, "net_bf16", net=dn, temp_moves=8, openings=1, reuse_subtree=True, rounds=2)
+    eng.reset_games()
+    for mv in range(6):
+        own, opp, tm_, st = eng.positions()
+        eng.search()
+        N, _, _ = eng.root_stats()
+        eng.status()
+        assert (N.sum(1) >= 200).all() and (mv == 0 or (N.sum(1) > 200).any())  # retained visits show up from move 2 on
+        eng.play(True)
+    t = eng.example_tensors()
+    assert _legal_per_oracle(t["own"][0, :, :6].cpu().numpy().view(np.uint64).ravel(), t["opp"][0, :, :6].cpu().numpy().view(np.uint64).ravel(),
+                             t["act"][0, :, :6].cpu().numpy().ravel())
