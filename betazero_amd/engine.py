@@ -285,14 +285,16 @@ def pack_examples(t, id_base, id_stride, size):
 
 
 def self_play(game, n_games, sims, net=None, seed=0, evaluator=None, temp_moves=0, openings=0, c_puct=1.5,
-              device="cuda:0", game_id_base=0, game_id_stride=None):
+              device="cuda:0", game_id_base=0, game_id_stride=None, dirichlet_alpha=0.0, dirichlet_eps=0.0,
+              reuse_subtree=False):
     """Play n_games concurrent self-play games to the end on one GPU and return
     (s, pi, z): canonical states int8 [n, size, size], visit-count policies
     f32 [n, NA], outcomes for the mover int8 [n] -- plus the Examples object."""
     if evaluator is None:
         evaluator = "net_bf16" if net is not None else "uniform"
     eng = SelfPlayEngine(game, n_games, sims, evaluator, net, c_puct, temp_moves, openings, seed, 1, game_id_base,
-                         game_id_stride, device)
+                         game_id_stride, device, dirichlet_alpha=dirichlet_alpha, dirichlet_eps=dirichlet_eps,
+                         reuse_subtree=reuse_subtree)
     eng.run_iteration()
     ex = eng.examples()
     return ex.states(), ex.pi, ex.z, ex
