@@ -272,18 +272,6 @@ def concat_examples(parts):
                     parts[0].size)
 
 
-def pack_examples(t, id_base, id_stride, size):
-    """[R,B,T,...] fixed-capacity arrays -> compact Examples (finished games only)"""
-    R, B, T = t["own"].shape
-    ln = t["len"]
-    valid = (np.arange(T)[None, None, :] < ln[:, :, None])
-    r, b, k = np.nonzero(valid)
-    gid = id_base + r.astype(np.int64) * id_stride + b
-    return Examples(own=t["own"][r, b, k].view(np.uint64), opp=t["opp"][r, b, k].view(np.uint64), pi=t["pi"][r, b, k],
-                    z=t["z"][r, b, k], mover=t["mover"][r, b, k], act=t["act"][r, b, k], game=gid,
-                    ply=k.astype(np.int32), size=size)
-
-
 def self_play(game, n_games, sims, net=None, seed=0, evaluator=None, temp_moves=0, openings=0, c_puct=1.5,
               device="cuda:0", game_id_base=0, game_id_stride=None, dirichlet_alpha=0.0, dirichlet_eps=0.0,
               reuse_subtree=False):

@@ -18,6 +18,8 @@ Fixtures:
                                 search is reference-computed)
   F9 minimax_players.npz        decisions of the reference's OptimalPlayer classes
                                 (Reversi depth-limited minimax, TTT full minimax)
+  F10 mcts_twin_features.*      the twin over the reference's boards with Dirichlet
+                                root noise / subtree reuse switched on
 
 Run:  python oracle/gen_golden.py
 """
@@ -227,8 +229,8 @@ def gen_f5_f6():
 class Twin(_Twin):
     """oracle/py_twin.py bound to the REFERENCE's board classes"""
 
-    def __init__(self, game, eval_kind, c_puct=1.5):
-        super().__init__(game, eval_kind, c_puct, boards=(ReversiBoard, TicTacToeBoard))
+    def __init__(self, game, eval_kind, c_puct=1.5, **kw):
+        super().__init__(game, eval_kind, c_puct, boards=(ReversiBoard, TicTacToeBoard), **kw)
 
 
 
@@ -355,6 +357,31 @@ def gen_f8():
     print("F8", len(st), "augmented rows")
 
 
+# ---------------------------------------------------------------- F10: opt-in search features over the reference's boards
+def gen_f10():
+    """self-play games of the twin over the REFERENCE's board objects with the opt-in search features of DESIGN.md 3.9 /
+    3.10 (Dirichlet root noise, subtree reuse, both), so that these too are pinned with every env transition
+    reference-computed: mcts_twin_features.npz / .json"""
+    out, meta = {}, {"cases": []}
+    cases = [("ttt", "hash", 1, 30, 3, 0, 7, 0.0, 0.0, True), ("ttt", "uniform", 2, 40, 2, 0, 1, 0.3, 0.25, False),
+             ("reversi", "hash", 4, 16, 6, 1, 3, 0.5, 0.25, True), ("reversi", "hash", 9, 20, 8, 1, 0, 0.0, 0.0, True),
+             ("reversi6", "hash", 3, 20, 4, 0, 5, 1.0, 0.5, True), ("reversi4", "hash", 1, 40, 4, 0, 2, 0.3, 0.25, True),
+             ("reversi4", "hash", 2, 40, 4, 0, 7, 0.0, 0.0, True)]
+    for ci, (game, ev, gid, sims, tmv, openings, seed, alpha, eps, reuse) in enumerate(cases):
+        tw = Twin(game, ev, dir_alpha=alpha, dir_eps=eps, reuse=reuse)
+        ex, w, passes = tw.selfplay(gid, sims, tmv, openings, seed)
+        out[f"g{ci}_own"] = np.array([e[0] for e in ex], dtype=np.uint64)
+        out[f"g{ci}_pi"] = np.array([e[2] for e in ex], dtype=np.float32)
+        out[f"g{ci}_act"] = np.array([e[4] for e in ex], dtype=np.uint8)
+        meta["cases"].append({"id": ci, "game": game, "eval": ev, "gid": gid, "sims": sims, "temp_moves": tmv,
+                              "openings": openings, "seed": seed, "alpha": alpha, "eps": eps, "reuse": reuse,
+                              "winner": int(w), "passes": passes})
+    np.savez_compressed(os.path.join(OUT, "mcts_twin_features.npz"), **out)
+    with open(os.path.join(OUT, "mcts_twin_features.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("F10", len(cases), "cases; passes:", [c["passes"] for c in meta["cases"]])
+
+
 # ---------------------------------------------------------------- F9: the reference's minimax players
 def _load_by_path(name, path):
     import importlib.util
@@ -449,7 +476,7 @@ def gen_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8", "f9"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10"]
     if "f1" in which: gen_f1()
     if "f2" in which: gen_f2()
     if "f3" in which: gen_f3()
@@ -458,3 +485,4 @@ if __name__ == "__main__":
     if "f7" in which: gen_f7()
     if "f8" in which: gen_f8()
     if "f9" in which: gen_f9()
+    if "f10" in which: gen_f10()

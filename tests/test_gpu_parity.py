@@ -1103,3 +1103,17 @@ def test_subtree_reuse_selfplay_vs_oracle_bitexact():
     t = eng.example_tensors()
     assert _legal_per_oracle(t["own"][0, :, :6].cpu().numpy().view(np.uint64).ravel(), t["opp"][0, :, :6].cpu().numpy().view(np.uint64).ravel(),
                              t["act"][0, :, :6].cpu().numpy().ravel())
+
+
+def test_search_features_match_the_twin_over_reference_boards_fixture():
+    """fixture F10 (twin over the REFERENCE's boards, root noise / subtree reuse on): the engine's games equal it"""
+    d = np.load(os.path.join(G, "mcts_twin_features.npz"))
+    for c in json.load(open(os.path.join(G, "mcts_twin_features.json")))["cases"]:
+        eng = _engine(c["game"], 1, c["sims"], c["eval"], temp_moves=c["temp_moves"], openings=c["openings"], seed=c["seed"],
+                      game_id_base=c["gid"], dirichlet_alpha=c["alpha"], dirichlet_eps=c["eps"], reuse_subtree=c["reuse"])
+        eng.run_iteration()
+        ex = eng.examples()
+        i = c["id"]
+        assert np.array_equal(ex.own, d[f"g{i}_own"]) and np.array_equal(ex.act, d[f"g{i}_act"]), c
+        assert np.array_equal(ex.pi.view(np.uint32), d[f"g{i}_pi"].view(np.uint32)), c
+        assert eng.winners()[0][0, 0] == c["winner"]
