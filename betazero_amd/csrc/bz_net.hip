@@ -185,25 +185,31 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
 constexpr int kTC = 128;                  // channels of the benchmark net (the fp8 tower serves only this width)
 
 // Geometry of the fused bf16 net kernel for C = 64, 128 or 256 channels.  A workgroup of 4 waves keeps P positions
-// resident in LDS (2 buffers x P x TILE = 133 KB for every width: one workgroup per CU) and its 32 accumulator tiles
-// (MT M-tiles of 32 output channels x P positions x 2 cell tiles) are dealt 8 per wave as MW M-tiles x PW positions:
+// resident in LDS and its accumulator tiles (MT M-tiles of 32 output channels x P positions x 2 cell tiles) are
+// dealt to the waves as MW M-tiles x PW positions each.
+// Throughput shape (P = 512 / C: 2 buffers x P x TILE = 133 KB of LDS for every width, one workgroup per CU):
 //   C =  64: P = 8, wave w -> M-tile  w & 1,        positions 4 (w >> 1) .. +3   (MW 1, PW 4)
 //   C = 128: P = 4, wave w -> M-tile  w,            positions 0 .. 3             (MW 1, PW 4)   <- the benchmark net
 //   C = 256: P = 2, wave w -> M-tiles 2w, 2w + 1,   positions 0, 1               (MW 2, PW 2)
+// Latency shape for small batches (P = 1; 2 at C = 64): one position per workgroup -- a batch of up to 256 positions
+// then spreads over as many CUs instead of 4 positions sharing one (an interactive MCTSPlayer search is B = 1: the
+// throughput shape would compute three padding positions for every real one).
 // (Round 1 measured 2 positions x 2 workgroups per CU, a tile-major last tap and the 16x16x32 MFMA shape, round 2 the
 // MW = 2 split at C = 128: all within +-1 % because the kernel sits on the power-limited clock -- DESIGN.md 5.)
-template <int C> struct Tw {
-    static_assert(C == 64 || C == 128 || C == 256, "the MFMA tower is built for 64, 128 or 256 channels");
+template <int C_, int P_ = 512 / C_> struct Tw {
+    static_assert(C_ == 64 || C_ == 128 || C_ == 256, "the MFMA tower is built for 64, 128 or 256 channels");
+    static constexpr int C = C_;
     static constexpr int KC = C / 16;                  // k-steps (16 input channels) per conv tap
     static constexpr int MT = C / 32;                  // M-tiles (32 output channels)
     static constexpr int CELL = 2 * C;                 // bytes of one board cell (all channels, bf16)
     static constexpr int ZERO = C == 64 ? 256 : CELL;  // zero region read by the conv halo (128-B cells: one per x parity)
     static constexpr int TILE = 64 * CELL + ZERO;      // bytes of one position
-    static constexpr int P = 512 / C;                  // positions resident per workgroup
+    static constexpr int P = P_;                       // positions resident per workgroup
     static constexpr int BUF = P * TILE;
     static constexpr int LDS = 2 * BUF;
     static constexpr int MW = MT >= 8 ? 2 : 1;         // M-tiles per wave
-    static constexpr int PW = 4 / MW;                  // positions per wave
+    static constexpr int PW = MT * P / 4 / MW;         // positions per wave
+    static_assert(MW * PW * 4 == MT * P && PW >= 1, "the (M-tile, position) units must split evenly over 4 waves");
     static constexpr int NG = MT / MW;                 // wave groups along M
     static constexpr int KS = KC < 8 ? KC : 8;         // k-steps per weight-prefetch chunk (register set)
     static constexpr int CPT = KC / KS;                // chunks per tap
@@ -234,9 +240,8 @@ __device__ unsigned long long g_dbg[8 * 4096];
 
 // LDS byte offsets (inside a position tile) of the B-operand chunk h of k-step 0 for conv tap `tap`, for the lane's
 // two cell tiles; load_b XORs the k-step in.
-template <int C>
+template <class G>
 __device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
-    typedef Tw<C> G;
     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -245,26 +250,26 @@ __device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
         // out of the board -> the zero region.  The swizzle comes from the UNCLAMPED coordinates: a halo lane then
         // reads the slot of the zero region that its virtual cell would occupy, so the 16 lanes of a ds_read_b128
         // group still hit 16 distinct slots (no bank conflict between halo and board lanes)
-        int base = inb ? (yy * 8 + xx) * G::CELL : 64 * G::CELL + (C == 64 ? (xx & 1) * 128 : 0);
+        int base = inb ? (yy * 8 + xx) * G::CELL : 64 * G::CELL + (G::C == 64 ? (xx & 1) * 128 : 0);
         boff[nt] = base + ((G::sw(yy, xx) ^ h) << 4);
     }
 }
-template <int C>
-__device__ __forceinline__ void load_b(bf16x8 (&b)[Tw<C>::PW][2], const char* in, const int (&boff)[2], int kc) {
+template <class G>
+__device__ __forceinline__ void load_b(bf16x8 (&b)[G::PW][2], const char* in, const int (&boff)[2], int kc) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const char* bp = in + (boff[nt] ^ (kc << 5));  // chunk 2 kc + h: the XOR stays inside the cell
 #pragma unroll
-        for (int p = 0; p < Tw<C>::PW; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * Tw<C>::TILE);
+        for (int p = 0; p < G::PW; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * G::TILE);
     }
 }
-template <int C>
-__device__ __forceinline__ void mfma8(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], const bf16x8 (&a)[Tw<C>::MW],
-                                      const bf16x8 (&b)[Tw<C>::PW][2]) {
+template <class G>
+__device__ __forceinline__ void mfma8(f32x16 (&acc)[G::MW][G::PW][2], const bf16x8 (&a)[G::MW],
+                                      const bf16x8 (&b)[G::PW][2]) {
 #pragma unroll
-    for (int mt = 0; mt < Tw<C>::MW; ++mt)
+    for (int mt = 0; mt < G::MW; ++mt)
 #pragma unroll
-        for (int p = 0; p < Tw<C>::PW; ++p)
+        for (int p = 0; p < G::PW; ++p)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
                 acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[p][nt], acc[mt][p][nt], 0, 0, 0);
@@ -275,12 +280,11 @@ __device__ __forceinline__ void mfma8(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], co
 // whole chunk ahead; the fragment stream is linear over chunks, taps and layers).  Activation fragments are double-
 // buffered (b0/b1): the ds_read_b128 of k-step k+1 are issued between the MFMAs of k-step k.  `in` points at the wave's
 // first position; (boff, kc0) address this chunk, (tap_n, kc0_n) the next one.
-template <int S, int C>
-__device__ __forceinline__ void chunk_step(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], bf16x8 (&A0)[Tw<C>::KS][Tw<C>::MW],
-                                           bf16x8 (&A1)[Tw<C>::KS][Tw<C>::MW], const uint4*& ap, const char* in,
+template <int S, class G>
+__device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::PW][2], bf16x8 (&A0)[G::KS][G::MW],
+                                           bf16x8 (&A1)[G::KS][G::MW], const uint4*& ap, const char* in,
                                            int (&boff)[2], int kc0, int tap_n, int kc0_n, int r, int h,
-                                           bf16x8 (&b0)[Tw<C>::PW][2], bf16x8 (&b1)[Tw<C>::PW][2]) {
-    typedef Tw<C> G;
+                                           bf16x8 (&b0)[G::PW][2], bf16x8 (&b1)[G::PW][2]) {
     bf16x8 (&use)[G::KS][G::MW] = S ? A1 : A0;
     bf16x8 (&nxt)[G::KS][G::MW] = S ? A0 : A1;
 #pragma unroll
@@ -289,14 +293,14 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2
         for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
     ap += G::KS * G::MT * 64;
     int boff_n[2];
-    tap_off<C>(tap_n, r, h, boff_n);
+    tap_off<G>(tap_n, r, h, boff_n);
 #pragma unroll
     for (int k2 = 0; k2 < G::KS / 2; ++k2) {
-        load_b<C>(b1, in, boff, kc0 + 2 * k2 + 1);
-        mfma8<C>(acc, use[2 * k2], b0);
-        if (k2 < G::KS / 2 - 1) load_b<C>(b0, in, boff, kc0 + 2 * k2 + 2);
-        else load_b<C>(b0, in, boff_n, kc0_n);  // first k-step of the next chunk
-        mfma8<C>(acc, use[2 * k2 + 1], b1);
+        load_b<G>(b1, in, boff, kc0 + 2 * k2 + 1);
+        mfma8<G>(acc, use[2 * k2], b0);
+        if (k2 < G::KS / 2 - 1) load_b<G>(b0, in, boff, kc0 + 2 * k2 + 2);
+        else load_b<G>(b0, in, boff_n, kc0_n);  // first k-step of the next chunk
+        mfma8<G>(acc, use[2 * k2 + 1], b1);
     }
 #pragma unroll
     for (int i = 0; i < G::KS; ++i) {
@@ -322,10 +326,9 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2
 // +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]: lane (r, h) register 4q+i of M-tile wt
 // holds co = 32wt + 8q + 4h + i of cell 32nt + r, i.e. 4 consecutive channels = one 8-byte store.
 // `out` points at the wave's first position.
-template <int C>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2], char* out, bool second,
+template <class G>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::PW][2], char* out, bool second,
                                          const float* __restrict__ bl, int wt0, int r, int h) {
-    typedef Tw<C> G;
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt) {
         const int wt = wt0 + mt;
@@ -356,11 +359,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[Tw<C>::MW][Tw<C>::PW][2],
 
 // One conv3x3 layer over the resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
 // S0 = register set that holds chunk 0's weight fragments on entry; on exit it is set S0 ^ (NCH & 1).
-template <int S0, int C>
+template <int S0, class G>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
-                                           bf16x8 (&A0)[Tw<C>::KS][Tw<C>::MW], bf16x8 (&A1)[Tw<C>::KS][Tw<C>::MW],
+                                           bf16x8 (&A0)[G::KS][G::MW], bf16x8 (&A1)[G::KS][G::MW],
                                            const uint4*& ap, int w, int r, int h, unsigned long long (&tacc)[4]) {
-    typedef Tw<C> G;
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
     f32x16 acc[G::MW][G::PW][2];
@@ -371,26 +373,31 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     const int wpos = G::pos0(w) * G::TILE;
     in += wpos; out += wpos;
     int boff[2];
-    tap_off<C>(0, r, h, boff);
+    tap_off<G>(0, r, h, boff);
     bf16x8 b0[G::PW][2], b1[G::PW][2];
-    load_b<C>(b0, in, boff, 0);
+    load_b<G>(b0, in, boff, 0);
     // chunk c covers tap c / CPT, k-steps (c % CPT) * KS ..; the chunk after the last one is a harmless re-read
     auto tap_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return c / G::CPT; };
     auto kc0_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return (c % G::CPT) * G::KS; };
 #pragma unroll 1
     for (int c = 0; c + 1 < G::NCH; c += 2) {
-        chunk_step<S0, C>(acc, A0, A1, ap, in, boff, kc0_of(c), tap_of(c + 1), kc0_of(c + 1), r, h, b0, b1);
-        chunk_step<1 - S0, C>(acc, A0, A1, ap, in, boff, kc0_of(c + 1), tap_of(c + 2), kc0_of(c + 2), r, h, b0, b1);
+        chunk_step<S0, G>(acc, A0, A1, ap, in, boff, kc0_of(c), tap_of(c + 1), kc0_of(c + 1), r, h, b0, b1);
+        chunk_step<1 - S0, G>(acc, A0, A1, ap, in, boff, kc0_of(c + 1), tap_of(c + 2), kc0_of(c + 2), r, h, b0, b1);
     }
     if (G::NCH & 1)
-        chunk_step<S0, C>(acc, A0, A1, ap, in, boff, kc0_of(G::NCH - 1), tap_of(G::NCH), kc0_of(G::NCH), r, h, b0, b1);
+        chunk_step<S0, G>(acc, A0, A1, ap, in, boff, kc0_of(G::NCH - 1), tap_of(G::NCH), kc0_of(G::NCH), r, h, b0, b1);
     BZ_STAMP(t1);
-    epilogue<C>(acc, out, second, bl, G::wt0(w), r, h);
+    epilogue<G>(acc, out, second, bl, G::wt0(w), r, h);
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);
     tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
 }
+
+typedef Tw<64, 2> TwS64;     // latency shapes: the smallest P whose (M-tile, position) units fill 4 waves
+typedef Tw<128, 1> TwS128;
+typedef Tw<256, 1> TwS256;
+constexpr int kSmallBatch = 256;  // one workgroup per position and per CU up to here
 
 struct TowerArgs {
     const u64 *own, *opp;            // [n] bitboards, side-to-move canonical
@@ -436,11 +443,10 @@ __device__ __forceinline__ float wave_sum(float x) {
 // The whole net forward for P positions per workgroup: stem (MFMA, K = 18 padded to 32, fed from
 // the bitboards) -> residual tower (activations resident in LDS) -> heads (conv1x1 by MFMA, the
 // small FCs by one wave per position).  HBM traffic per position: 16 B in, 264 B out.
-template <int C>
+template <class G>
 __global__ void __launch_bounds__(256, 1)
 k_tower_bf16(TowerArgs T) {
-    typedef Tw<C> G;
-    constexpr int P = G::P, PW = G::PW, MW = G::MW;
+    constexpr int C = G::C, P = G::P, PW = G::PW, MW = G::MW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -497,15 +503,15 @@ k_tower_bf16(TowerArgs T) {
                 }
             }
         }
-        epilogue<C>(acc, bufX + wp0 * G::TILE, false, T.stem_b, wt0, r, h);
+        epilogue<G>(acc, bufX + wp0 * G::TILE, false, T.stem_b, wt0, r, h);
     }
     __syncthreads();
 
     // ---- tower: a residual block = conv1 (X -> M) + conv2 (M -> X in place, + skip X)
 #pragma unroll 1
     for (int blk = 0; blk < T.n_layers / 2; ++blk) {
-        conv_layer<0, C>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * C, A0, A1, ap, w, r, h, tacc);
-        conv_layer<(G::NCH & 1), C>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * C, A0, A1, ap, w, r, h, tacc);
+        conv_layer<0, G>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * C, A0, A1, ap, w, r, h, tacc);
+        conv_layer<(G::NCH & 1), G>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * C, A0, A1, ap, w, r, h, tacc);
     }
     BZ_STAMP(tk1);
 
@@ -1080,9 +1086,10 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     if (urc != BZ_OK) { delete n; return urc; }
     {
         hipError_t e3 = hipSuccess;
-        if (C == 64) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<64>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<64>::LDS);
-        if (C == 128) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<128>::LDS);
-        if (C == 256) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<256>::LDS);
+        if (C == 64) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<Tw<64>>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<64>::LDS);
+        if (C == 128) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<Tw<128>>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<128>::LDS);
+        if (C == 256) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<Tw<256>>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<256>::LDS);
+        // (the latency shapes use under 64 KB of LDS: no attribute needed)
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
         // the f32 parity kernels stage a whole position in LDS: above 64 KB at C = 256
         if (C == 256) {
@@ -1166,12 +1173,15 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     {
         ProfScope ps(BZ_PROF_TOWER, stream);
         if (fp8) hipLaunchKernelGGL(f8::k_tower_fp8, dim3((cnt + 3) / 4), dim3(256), f8::kLds, s, T);
-        else if (n->C == 64)
-            hipLaunchKernelGGL(k_tower_bf16<64>, dim3((cnt + Tw<64>::P - 1) / Tw<64>::P), dim3(256), Tw<64>::LDS, s, T);
-        else if (n->C == 256)
-            hipLaunchKernelGGL(k_tower_bf16<256>, dim3((cnt + Tw<256>::P - 1) / Tw<256>::P), dim3(256), Tw<256>::LDS, s, T);
-        else
-            hipLaunchKernelGGL(k_tower_bf16<128>, dim3((cnt + Tw<128>::P - 1) / Tw<128>::P), dim3(256), Tw<128>::LDS, s, T);
+        else {
+            // up to kSmallBatch positions: one (two at C = 64) per workgroup, i.e. per CU -- the latency shape
+            const bool small = cnt <= kSmallBatch;
+#define BZ_TOWER_LAUNCH(GEOM) hipLaunchKernelGGL(k_tower_bf16<GEOM>, dim3((cnt + GEOM::P - 1) / GEOM::P), dim3(256), GEOM::LDS, s, T)
+            if (n->C == 64) { if (small) BZ_TOWER_LAUNCH(TwS64); else BZ_TOWER_LAUNCH(Tw<64>); }
+            else if (n->C == 256) { if (small) BZ_TOWER_LAUNCH(TwS256); else BZ_TOWER_LAUNCH(Tw<256>); }
+            else { if (small) BZ_TOWER_LAUNCH(TwS128); else BZ_TOWER_LAUNCH(Tw<128>); }
+#undef BZ_TOWER_LAUNCH
+        }
     }
     BZ_LAUNCH_CHECK("k_tower_bf16");
     return BZ_OK;
