@@ -5,9 +5,10 @@ Default workload = BASELINE config 3: Reversi 8x8, 4096 concurrent games per GPU
 800 MCTS simulations per move, random-init 6x128 conv policy/value net in bf16
 (MFMA), tau=1 for moves < 8 + 12 fixed two-ply openings.  `--workload ttt` runs
 BASELINE config 2 (65,536 TTT games, 50 sims, uniform priors, tree kernels only),
-`--workload net` config 5 (net forward only, batch 8192, fp8).  The default run also
-measures configs 2 and 5 briefly after the headline measurement and attaches them
-as `secondary` (driver-timed evidence for their rooflines; not part of `value`).
+`--workload net` config 5 (net forward only, batch 8192, fp8), `--workload env` the
+batched board-env step kernel alone.  The default run also measures configs 2 and 5
+and the env step briefly after the headline measurement and attaches them as
+`secondary` (driver-timed evidence for their rooflines; not part of `value`).
 
 A "step" (reversi) = one move for every concurrent game: root expansion + 800 x
 (select -> net -> expand/backup) + move choice / example row / env step.  The
@@ -300,6 +301,55 @@ def run_net(ctx, B, K, W, fp8):
                          "avg_launch_ms": avg_ms, "flop_per_launch": B * NET_FLOP_PER_POS}}
 
 
+def run_env(ctx, n, K, W):
+    """the batched board-env step on its own (bz_reversi_step_batch: legal-move mask, apply-move / flip, terminal /
+    winner for n games per launch; 42 algorithmic bytes per step): every game plays the lowest legal
+    move of a random position (pass where there is none)"""
+    import torch
+    from betazero_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=ctx.dev).manual_seed(0)
+    a = torch.randint(0, 2**62, (n,), generator=g, device=ctx.dev, dtype=torch.int64)
+    b = torch.randint(0, 2**62, (n,), generator=g, device=ctx.dev, dtype=torch.int64)
+    own, opp = a & ~b, b & ~a
+    legal = torch.empty(n, dtype=torch.int64, device=ctx.dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.bz_reversi_legal_batch(own.data_ptr(), opp.data_ptr(), n, legal.data_ptr(), st))
+    low = legal & -legal  # stones live in bits 0..61, so the lowest legal bit is a positive power of two (exact in f64)
+    action = torch.where(legal == 0, torch.full_like(legal, 64), torch.log2(low.clamp(min=1).double()).long()).to(torch.uint8)
+    on, pn, ln = (torch.empty(n, dtype=torch.int64, device=ctx.dev) for _ in range(3))
+    status = torch.empty(n, dtype=torch.uint8, device=ctx.dev)
+    winner = torch.empty(n, dtype=torch.int8, device=ctx.dev)
+
+    def step():
+        _lib.check(L.bz_reversi_step_batch(own.data_ptr(), opp.data_ptr(), action.data_ptr(), n, on.data_ptr(),
+                                           pn.data_ptr(), ln.data_ptr(), status.data_ptr(), winner.data_ptr(), st))
+    for _ in range(W):
+        step()
+    L.bz_profile_reset()
+    L.bz_profile_reserve(_lib.PROF_SLOTS.index("env_step"), K + 8)
+    L.bz_profile_enable(1)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    L.bz_profile_enable(0)
+    launches, timed, ms = _lib.profile_read()["env_step"]
+    assert launches == timed == K and int((status == _lib.ST_ILLEGAL).sum()) == 0
+    avg_ms = ms / timed
+    ach = 42.0 * n / (avg_ms * 1e-3) / 1e9
+    return {"metric": "env_steps_per_s", "value": n * K * ctx.world / dt, "unit": "steps/s", "n_gpus": ctx.world, "steps": K,
+            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"reversi8x8_env_step_{n}games", "positions": "random stones, lowest legal move"},
+            "roofline": {"bound": "hbm", "kernel": "k_reversi_step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": 42.0 * n,
+                         "note": "VALU-bound: ~470 int32 operations per 42-byte step (profiles/r02_pmc_env_*)"}}
+
+
 def run_ttt(ctx, B, sims, K, W):
     """BASELINE cfg 2: TTT, uniform priors, the whole search of a move is one fused tree kernel"""
     from betazero_amd import _lib
@@ -508,8 +558,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt", "net"],
-                    help="reversi = BASELINE cfg 3 (default, the metric), ttt = cfg 2, net = cfg 5 (net forward only)")
+    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt", "net", "env"],
+                    help="reversi = BASELINE cfg 3 (default, the metric), ttt = cfg 2, net = cfg 5 (net forward only), "
+                         "env = the batched board-env step kernel alone")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -573,6 +624,9 @@ def main():
     if args.workload == "net":  # BASELINE cfg 5: leaf-eval batch 8192, fp8 e4m3 net, MFMA-utilisation run
         out = run_net(ctx, args.games or 8192, args.steps if args.steps is not None else 1000,
                       args.warmup if args.warmup is not None else 50, (args.precision or "fp8") == "fp8")
+    elif args.workload == "env":
+        out = run_env(ctx, args.games or (1 << 26), args.steps if args.steps is not None else 20,
+                      args.warmup if args.warmup is not None else 3)
     elif args.workload == "ttt":
         sims = args.sims or 50
         out = run_ttt(ctx, args.games or 65536, sims, args.steps if args.steps is not None else 20,
@@ -587,7 +641,8 @@ def main():
             if not args.no_secondary:  # cfg 2 and cfg 5 in the same driver-timed process (a few seconds)
                 sec = {}
                 for name, fn in (("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
-                                 ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True))):
+                                 ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
+                                 ("env_step", lambda: run_env(ctx, 1 << 25, 20, 3))):
                     try:
                         note(f"secondary {name}")
                         r = fn()

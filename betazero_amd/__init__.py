@@ -7,8 +7,8 @@ and raises when no HIP device is present -- there is no CPU fallback."""
 from .reversi import ReversiBoard, ReversiHeadless  # noqa: F401
 from .tic_tac_toe import TicTacToeBoard, TicTacToeHeadless, process_game_positions  # noqa: F401
 from .players import (Player, ReversiPlayer, RandomPlayer, ReversiRandomPlayer, MCTSPlayer, MinimaxPlayer,  # noqa: F401
-                      OptimalPlayer, ReversiOptimalPlayer)
+                      OptimalPlayer, ReversiOptimalPlayer, NetPlayer)
 
 __all__ = ["ReversiBoard", "ReversiHeadless", "TicTacToeBoard", "TicTacToeHeadless", "process_game_positions",
            "Player", "ReversiPlayer", "RandomPlayer", "ReversiRandomPlayer", "MCTSPlayer", "MinimaxPlayer",
-           "OptimalPlayer", "ReversiOptimalPlayer"]
+           "OptimalPlayer", "ReversiOptimalPlayer", "NetPlayer"]

@@ -116,6 +116,33 @@ class ReversiOptimalPlayer(ReversiPlayer):
         return best_move
 
 
+class NetPlayer(ReversiPlayer):
+    """The net-only player: AIPlayer.get_move (src/tic_tac_toe/players.py:84-98) for 8x8 Reversi and the conv
+    policy/value net -- canonicalise the position for the side to move (:85), one forward (:86), play the best LEGAL
+    move in descending-logit order (:92-98; ties -> lowest action, where torch.sort leaves them unspecified)."""
+
+    def __init__(self, symbol, net, precision="bf16"):
+        self.symbol, self.net, self.precision = symbol, net, precision
+        self.last_logits = None
+
+    def get_move(self, board):
+        import torch
+        if getattr(board, "size", 8) != 8:
+            raise ValueError("the conv net serves 8x8 Reversi only")
+        own, opp = board.bits(self.symbol)
+        o = torch.as_tensor(np.array([own], dtype=np.uint64).view(np.int64)).to(self.net.device)
+        p = torch.as_tensor(np.array([opp], dtype=np.uint64).view(np.int64)).to(self.net.device)
+        lg, _ = self.net.forward(o, p, bf16=self.precision != "f32", fp8=self.precision == "fp8")
+        lg = lg[0, :64].cpu().numpy()
+        self.last_logits = lg
+        moves = board.generate_possible_moves(self.symbol)
+        if not moves:
+            return (None, None)
+        idx = np.array([8 * r + c for r, c in moves])
+        best = idx[np.argmax(lg[idx])]  # generate_possible_moves is row-major: the first maximum is the lowest action
+        return int(best) // 8, int(best) % 8
+
+
 class MCTSPlayer(Player):
     """get_move(board) -> (row, col) by one GPU search (PUCT, `sims` simulations)
     from `board` with `symbol` to move; plays argmax visit count (ties -> lowest

@@ -1117,3 +1117,39 @@ def test_search_features_match_the_twin_over_reference_boards_fixture():
         assert np.array_equal(ex.own, d[f"g{i}_own"]) and np.array_equal(ex.act, d[f"g{i}_act"]), c
         assert np.array_equal(ex.pi.view(np.uint32), d[f"g{i}_pi"].view(np.uint32)), c
         assert eng.winners()[0][0, 0] == c["winner"]
+
+
+def test_net_player_follows_the_reference_aiplayer_rule():
+    """NetPlayer = AIPlayer.get_move (players.py:84-98) on the conv net: canonical input for the side to move, best LEGAL
+    move in descending-logit order.  With the exact-fp32 path the choice must be the oracle's, for both colours,
+    over a whole game against a random opponent driven by the reference-style loop."""
+    import random
+    import betazero_amd as bz
+    from betazero_amd.net import DeviceNet
+    m = _net(32, 2, seed=9)
+    dn, on = DeviceNet.from_module(m, 4), orc.Net(32, 2, 64, m.flat_params())
+    random.seed(4)
+    for sym in (1, -1):
+        pl = bz.NetPlayer(sym, dn, precision="f32")
+        other = bz.ReversiRandomPlayer(-sym)
+        g = bz.ReversiHeadless(pl if sym == 1 else other, other if sym == 1 else pl)
+        b, cur, n_checked = bz.ReversiBoard(), 1, 0
+        while not b.is_game_over():
+            mv = b.generate_possible_moves(cur)
+            if mv:
+                if cur == sym:
+                    r, c = pl.get_move(b)
+                    own, opp = b.bits(sym)
+                    olg, _ = on.forward(np.array([own], np.uint64), np.array([opp], np.uint64))
+                    assert np.array_equal(pl.last_logits.view(np.uint32), olg[0, :64].view(np.uint32))
+                    idx = [8 * rr + cc for rr, cc in mv]
+                    assert 8 * r + c == idx[int(np.argmax(olg[0][idx]))]
+                    n_checked += 1
+                else:
+                    r, c = other.get_move(b)
+                b = b.make_move(r, c, cur)
+            cur = -cur
+        assert n_checked > 20
+        del g
+    pl = bz.NetPlayer(1, DeviceNet.from_module(_net(128, 6, bf16=True), 4))  # the bf16 MFMA path (latency shape, B = 1)
+    assert pl.get_move(bz.ReversiBoard()) in bz.ReversiBoard().generate_possible_moves(1)
