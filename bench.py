@@ -316,7 +316,8 @@ def run_env(ctx, n, K, W):
     st = torch.cuda.current_stream().cuda_stream
     _lib.check(L.bz_reversi_legal_batch(own.data_ptr(), opp.data_ptr(), n, legal.data_ptr(), st))
     low = legal & -legal  # stones live in bits 0..61, so the lowest legal bit is a positive power of two (exact in f64)
-    action = torch.where(legal == 0, torch.full_like(legal, 64), torch.log2(low.clamp(min=1).double()).long()).to(torch.uint8)
+    idx = torch.where(low < 0, torch.full_like(low, 63), torch.log2(low.clamp(min=1).double()).long())  # bit 63 is the sign
+    action = torch.where(legal == 0, torch.full_like(legal, 64), idx).to(torch.uint8)
     on, pn, ln = (torch.empty(n, dtype=torch.int64, device=ctx.dev) for _ in range(3))
     status = torch.empty(n, dtype=torch.uint8, device=ctx.dev)
     winner = torch.empty(n, dtype=torch.int8, device=ctx.dev)
