@@ -55,4 +55,7 @@ if has ab; then
     done
   done
 fi
+# the result databases are tens of MB: summarise here, ship only the summaries
+python3 tools/summarize_prof.py "$TAG" --out "$OUT/summary" >&2
+find "$OUT" -name "*_results.db" -delete
 ls -R "$OUT" | head -80 >&2
