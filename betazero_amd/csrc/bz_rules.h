@@ -41,75 +41,44 @@ BZ_HD u64 rev_valid(int size) {
     return m;
 }
 
-// Bitboards as two 32-bit halves for the device code: 64-bit shifts by a constant 0 < s < 32 become two full-rate
-// 32-bit operations (v_alignbit_b32 + a 32-bit shift) instead of the quarter-rate v_lshlrev_b64 / v_lshrrev_b64, on
-// which the VALU-bound board kernels spent a quarter of their instructions (profiles/r02_pmc_env_*).  Keeping the
-// halves apart through the whole parallel-prefix (rather than splitting per shift) stops the compiler from
-// re-fusing them into 64-bit shifts.
-struct B2 { u32 lo, hi; };
-BZ_HD B2 b2(u64 x) { B2 r; r.lo = (u32)x; r.hi = (u32)(x >> 32); return r; }
-BZ_HD u64 b2u(B2 x) { return ((u64)x.hi << 32) | (u64)x.lo; }
-BZ_HD B2 operator&(B2 a, B2 b) { B2 r; r.lo = a.lo & b.lo; r.hi = a.hi & b.hi; return r; }
-BZ_HD B2 operator|(B2 a, B2 b) { B2 r; r.lo = a.lo | b.lo; r.hi = a.hi | b.hi; return r; }
-BZ_HD bool b2any(B2 a) { return (a.lo | a.hi) != 0u; }
-template <int S> BZ_HD B2 shl(B2 x) {
-    B2 r;
-#if defined(__HIP_DEVICE_COMPILE__)
-    r.hi = __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - S);
-#else
-    r.hi = (x.hi << S) | (x.lo >> (32 - S));
-#endif
-    r.lo = x.lo << S;
-    return r;
-}
-template <int S> BZ_HD B2 shr(B2 x) {
-    B2 r;
-#if defined(__HIP_DEVICE_COMPILE__)
-    r.lo = __builtin_amdgcn_alignbit(x.hi, x.lo, S);
-#else
-    r.lo = (x.lo >> S) | (x.hi << (32 - S));
-#endif
-    r.hi = x.hi >> S;
-    return r;
-}
-
-// one direction pair (shift S left / right), parallel-prefix over runs of <= 6
+// one direction pair (shift s left / right), parallel-prefix over runs of <= 6
 // opponent stones; o is opp pre-masked against wrap for this direction.
-template <int S> BZ_HD B2 rev_moves_dir(B2 own, B2 o) {
-    B2 fl = o & shl<S>(own), fr = o & shr<S>(own);
-    fl = fl | (o & shl<S>(fl));      fr = fr | (o & shr<S>(fr));
-    B2 pl = o & shl<S>(o),           pr = o & shr<S>(o);
-    fl = fl | (pl & shl<2 * S>(fl)); fr = fr | (pr & shr<2 * S>(fr));
-    fl = fl | (pl & shl<2 * S>(fl)); fr = fr | (pr & shr<2 * S>(fr));
-    return shl<S>(fl) | shr<S>(fr);
+BZ_HD u64 rev_moves_dir(u64 own, u64 o, int s) {
+    u64 fl = o & (own << s), fr = o & (own >> s);
+    fl |= o & (fl << s);      fr |= o & (fr >> s);
+    u64 pl = o & (o << s),    pr = o & (o >> s);
+    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    return (fl << s) | (fr >> s);
 }
 
 // generate_possible_moves(player) as a mask; own = player's stones
 BZ_HD u64 rev_legal(u64 own, u64 opp, u64 valid) {
-    const B2 w = b2(own), o = b2(opp), oh = b2(opp & kInner);
-    B2 m = rev_moves_dir<1>(w, oh) | rev_moves_dir<8>(w, o) | rev_moves_dir<7>(w, oh) | rev_moves_dir<9>(w, oh);
-    return b2u(m) & ~(own | opp) & valid;
+    u64 oh = opp & kInner;
+    u64 m = rev_moves_dir(own, oh, 1) | rev_moves_dir(own, opp, 8) | rev_moves_dir(own, oh, 7) |
+            rev_moves_dir(own, oh, 9);
+    return m & ~(own | opp) & valid;
 }
 BZ_HD u64 rev_legal8(u64 own, u64 opp) { return rev_legal(own, opp, ~0ULL); }
 
 // stones flipped by placing on bit m (m must be a legal cell); the 8 rays of
 // make_move (reversi_board.py:49-58)
-template <int S> BZ_HD B2 rev_flips_dir(B2 own, B2 o, B2 m) {
+BZ_HD u64 rev_flips_dir(u64 own, u64 o, u64 m, int s) {
     // runs of <= 6 opponent stones next to m, parallel-prefix (2 + 2 + 2 cells)
-    B2 fl = o & shl<S>(m), fr = o & shr<S>(m);
-    fl = fl | (o & shl<S>(fl));      fr = fr | (o & shr<S>(fr));
-    B2 pl = o & shl<S>(o),           pr = o & shr<S>(o);
-    fl = fl | (pl & shl<2 * S>(fl)); fr = fr | (pr & shr<2 * S>(fr));
-    fl = fl | (pl & shl<2 * S>(fl)); fr = fr | (pr & shr<2 * S>(fr));
-    B2 out; out.lo = 0; out.hi = 0;
-    if (b2any(shl<S>(fl) & own)) out = out | fl;
-    if (b2any(shr<S>(fr) & own)) out = out | fr;
+    u64 fl = o & (m << s), fr = o & (m >> s);
+    fl |= o & (fl << s);      fr |= o & (fr >> s);
+    u64 pl = o & (o << s),    pr = o & (o >> s);
+    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    u64 out = 0;
+    if ((fl << s) & own) out |= fl;
+    if ((fr >> s) & own) out |= fr;
     return out;
 }
 BZ_HD u64 rev_flips(u64 own, u64 opp, u64 m) {
-    const B2 w = b2(own), o = b2(opp), oh = b2(opp & kInner), mm = b2(m);
-    return b2u(rev_flips_dir<1>(w, oh, mm) | rev_flips_dir<8>(w, o, mm) | rev_flips_dir<7>(w, oh, mm) |
-               rev_flips_dir<9>(w, oh, mm));
+    u64 oh = opp & kInner;
+    return rev_flips_dir(own, oh, m, 1) | rev_flips_dir(own, opp, m, 8) | rev_flips_dir(own, oh, m, 7) |
+           rev_flips_dir(own, oh, m, 9);
 }
 
 // ---- tic-tac-toe
