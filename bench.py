@@ -348,7 +348,9 @@ def run_env(ctx, n, K, W):
             "roofline": {"bound": "hbm", "kernel": "k_reversi_step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": 42.0 * n,
-                         "note": "VALU-bound: ~470 int32 operations per 42-byte step (profiles/r02_pmc_env_*)"}}
+                         "note": "bound by integer VALU issue, not HBM: 482 VALU instructions per step (228 flips + 191 legal mask + "
+                                 "I/O) at 4 cycles per wave64 instruction keep the VALU ~100 % busy "
+                                 "(SQ_ACTIVE_INST_VALU, profiles/r02_pmc_env_sq_pmc.csv)"}}
 
 
 def run_ttt(ctx, B, sims, K, W):
