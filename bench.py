@@ -422,7 +422,9 @@ def run_reversi(ctx, args, B, sims, K, W):
     streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(NS)]
     engs = [SelfPlayEngine("reversi", sizes[i], sims, "net_" + prec, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
                            game_id_base=ctx.rank * B + sum(sizes[:i]), game_id_stride=ctx.world * B, device=ctx.dev,
-                           stagger=PLIES_PER_GAME if args.mode == "steady" else 0) for i in range(NS)]
+                           stagger=PLIES_PER_GAME if args.mode == "steady" else 0, reuse_subtree=args.reuse_subtree,
+                           dirichlet_alpha=0.5 if args.dirichlet_eps > 0 else 0.0, dirichlet_eps=args.dirichlet_eps)
+            for i in range(NS)]
     for e in engs:
         e.reset_games()
     ctx.sync()
@@ -503,6 +505,8 @@ def run_reversi(ctx, args, B, sims, K, W):
                       "step": "one move for all concurrent games (steady-state pool, staggered starts)"
                       if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",
                       "pipelines": f"{NS} x {Bs} games on separate HIP streams",
+                      **({"supplementary_features": {"reuse_subtree": args.reuse_subtree, "dirichlet_eps": args.dirichlet_eps}}
+                         if (args.reuse_subtree or args.dirichlet_eps > 0) else {}),
                       "parallelism": f"games sharded over {ctx.world} GPU(s), one all-gather of the example blocks"
                                      + (f" ({pooled_bytes} bytes received per rank)" if pooled_bytes else "")}}
     peak = MFMA_PEAK_TFLOPS if prec == "bf16" else 2 * MFMA_PEAK_TFLOPS  # dense fp8 = 5 PF
@@ -577,6 +581,8 @@ def main():
                     help="reversi: steady = one move per step on a staggered pool (default); iteration = a step is a\n"
                          "complete self-play iteration from the start position to the last finished game (cross-check)")
     ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
+    ap.add_argument("--reuse-subtree", action="store_true", help="supplementary: keep the chosen child's subtree (DESIGN 3.10)")
+    ap.add_argument("--dirichlet-eps", type=float, default=0.0, help="supplementary: root noise weight (alpha 0.5; DESIGN 3.9)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
