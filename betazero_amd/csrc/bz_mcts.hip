@@ -258,25 +258,6 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
         float pr[kCH];
 #pragma unroll
         for (int k = 0; k < kCH; ++k) pr[k] = a[k] >= 0 ? fdiv(ex[k], s) : 0.0f;
-        if (leaf == 0 && E.dir_eps > 0.0f) {  // root of a search: P' = (1 - eps) P + eps eta, eta ~ Dirichlet(alpha)
-            const u64 gid = E.id_base + (u64)E.g_round[g] * E.id_stride + (u64)g, ply = (u64)E.g_moves[g];
-            float gm[kCH];
-#pragma unroll
-            for (int k = 0; k < kCH; ++k) gm[k] = a[k] >= 0 ? gamma_spec(E.dir_alpha, E.seed, gid, ply, sub + kGW * k) : 0.0f;
-            float gs = 0.0f;  // ascending-edge serial sum, as for the softmax
-#pragma unroll
-            for (int k = 0; k < kCH; ++k)
-                for (int j = 0; j < kGW && kGW * k + j < n; ++j) gs = gs + __shfl(gm[k], j, kGW);
-            if (gs > 0.0f) {
-                const float keep = 1.0f - E.dir_eps;
-#pragma unroll
-                for (int k = 0; k < kCH; ++k) {
-                    float t1 = keep * pr[k];
-                    float t2 = E.dir_eps * fdiv(gm[k], gs);
-                    pr[k] = t1 + t2;
-                }
-            }
-        }
 #pragma unroll
         for (int k = 0; k < kCH; ++k)
             if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = pr[k]; e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
@@ -400,8 +381,7 @@ __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, 
 // Subtree reuse: copy the subtree below node `src_root` of the previous move's arena to the front of
 // this move's arena, breadth first (Cheney): node 0 = the new root, a node's edges stay one contiguous block in
 // ascending action order, child ids and edge0 are rewritten.  One lane per game; a few hundred nodes per move.
-// Then, if enabled, a fresh Dirichlet draw on the root's stored priors (the noise of 3.9 for a root that is
-// not expanded anew).
+// (With noise on, k_root_noise then makes a fresh Dirichlet draw on the kept root's stored priors, as for a new root.)
 template <class G>
 __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_root) {
     const Node* sn = E.nodes_alt + (size_t)g * E.ncap;
@@ -428,20 +408,6 @@ __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_ro
         e_dst += n;
     }
     E.n_nodes[g] = n_dst; E.n_edges[g] = e_dst;
-    if (E.dir_eps > 0.0f) {
-        const u64 gid = E.id_base + (u64)E.g_round[g] * E.id_stride + (u64)g, ply = (u64)E.g_moves[g];
-        const int n = (int)(dn[0].info & 0xFFu);
-        float gs = 0.0f;
-        for (int i = 0; i < n; ++i) gs = gs + gamma_spec(E.dir_alpha, E.seed, gid, ply, i);
-        if (gs > 0.0f) {
-            const float keep = 1.0f - E.dir_eps;
-            for (int i = 0; i < n; ++i) {
-                float t1 = keep * de[i].P;
-                float t2 = E.dir_eps * fdiv(gamma_spec(E.dir_alpha, E.seed, gid, ply, i), gs);
-                de[i].P = t1 + t2;
-            }
-        }
-    }
 }
 
 template <class G>
@@ -466,6 +432,29 @@ __global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
         E.leaf_slot[g] = slot; E.c_own[slot] = E.g_own[g]; E.c_opp[slot] = E.g_opp[g];
     }
     if (g == 0) E.flags[FLAG_NEVAL] = 0;
+}
+
+// Dirichlet root noise, its own small kernel so that the sampler's registers stay out of the tree
+// kernels (inlined into the expansion it took k_tree_step from 78 to 129 VGPRs and the cfg-2 kernel from 93 to 219):
+// P' = (1 - eps) P + eps g / sum(g) over the root's edges in ascending action order, for every active game whose
+// root is expanded -- freshly (by the expand-only tree step before this launch) or kept from the previous move.
+__global__ void __launch_bounds__(64) k_root_noise(EngineDev E) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.B || E.g_state[g] != 0) return;
+    const Node r = E.nodes[(size_t)g * E.ncap];
+    const int n = (int)(r.info & 0xFFu);
+    if (n == 0 || r.legal == 0) return;  // not expanded / a forced-pass root (P = 1 stays)
+    Edge* ed = E.edges + (size_t)g * E.ecap + r.edge0;
+    const u64 gid = E.id_base + (u64)E.g_round[g] * E.id_stride + (u64)g, ply = (u64)E.g_moves[g];
+    float gs = 0.0f;
+    for (int i = 0; i < n; ++i) gs = gs + gamma_spec(E.dir_alpha, E.seed, gid, ply, i);
+    if (!(gs > 0.0f)) return;
+    const float keep = 1.0f - E.dir_eps;
+    for (int i = 0; i < n; ++i) {
+        float t1 = keep * ed[i].P;
+        float t2 = E.dir_eps * fdiv(gamma_spec(E.dir_alpha, E.seed, gid, ply, i), gs);
+        ed[i].P = t1 + t2;
+    }
 }
 
 // synthetic evaluators as a separate step (used by the step-by-step API)
@@ -960,7 +949,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     // measured on MI355X at 65,536 games x 50 sims (profiles/r02_cfg2_*): 2 lanes 0.185 ms, 4 lanes 0.190 ms, 8 lanes
     // 0.294 ms per launch; small batches keep 4 lanes so that the chip still sees a few waves per CU
     e->ttt_gw = cfg->n_games >= 32768 ? 2 : 4;
-    if (const char* gw = getenv("BZ_TTT_GW")) { int v = atoi(gw); if (v == 0 || v == 2 || v == 4 || v == 8) e->ttt_gw = v; }
+    if (const char* gw = getenv("BZ_TTT_GW")) { int v = atoi(gw); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8) e->ttt_gw = v; }
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
@@ -1093,11 +1082,13 @@ BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {
 BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     int ek = e->cfg.eval_kind;
-    if ((ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) && !e->dev.reuse) {
+    const bool noise = e->dev.dir_eps > 0.0f;
+    if ((ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) && !e->dev.reuse && !noise) {
         ProfScope ps(BZ_PROF_SEARCH_FUSED, stream);
         if (e->cfg.game == BZ_GAME_TTT && e->cfg.sims <= kTttFusedMaxSims && e->ttt_gw > 0) {
             const dim3 grid = grid_groups(e->dev.B, e->ttt_gw);
             switch (e->ttt_gw) {
+            case 1: hipLaunchKernelGGL(k_search_fused_ttt<1>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
             case 2: hipLaunchKernelGGL(k_search_fused_ttt<2>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
             case 8: hipLaunchKernelGGL(k_search_fused_ttt<8>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
             default: hipLaunchKernelGGL(k_search_fused_ttt<4>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
@@ -1112,8 +1103,13 @@ BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     int32_t rc;
     if ((rc = bz_engine_root_begin(e, stream)) != BZ_OK) return rc;
     if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
+    if (noise) {  // expand the roots on their own, then draw the noise, then start selecting
+        if ((rc = tree_step(e, 1, 0, 0, stream)) != BZ_OK) return rc;
+        hipLaunchKernelGGL(k_root_noise, dim3((e->dev.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->dev);
+        BZ_LAUNCH_CHECK("k_root_noise");
+    }
     for (int s = 0; s < e->cfg.sims; ++s) {  // expand+backup of leaf s-1 (s = 0: the root) fused with select s
-        if ((rc = tree_step(e, 1, 1, (uint32_t)s, stream)) != BZ_OK) return rc;
+        if ((rc = tree_step(e, (noise && s == 0) ? 0 : 1, 1, (uint32_t)s, stream)) != BZ_OK) return rc;
         if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
     }
     return tree_step(e, 1, 0, 0, stream);
