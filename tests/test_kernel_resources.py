@@ -1,0 +1,57 @@
+"""Register / spill budget of the hot kernels, read from the compiler's own metadata (hipcc -S cross-compiles for
+gfx950 without a GPU).  A feature that inlines into a tree kernel can silently double its registers -- round 2's
+Dirichlet sampler took k_tree_step from 78 to 129 VGPRs with SGPR spills until it got a kernel of its own -- so the
+budgets are pinned here."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _resources(src, tmp_path):
+    out = tmp_path / (os.path.basename(src) + ".s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
+                           "-S", "-o", str(out), os.path.join(ROOT, "betazero_amd", "csrc", src)],
+                          stderr=subprocess.DEVNULL)
+    res = {}
+    txt = out.read_text()
+    for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if name:
+            g = lambda k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))  # noqa: E731
+            res[name.group(1)] = {"vgpr": g("vgpr_count"), "vspill": g("vgpr_spill_count"), "sspill": g("sgpr_spill_count"),
+                                  "scratch": g("private_segment_fixed_size")}
+    return res
+
+
+def _find(res, *parts):
+    hits = [k for k in res if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, hits)
+    return res[hits[0]]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_tree_kernels_stay_within_their_register_budget(tmp_path):
+    res = _resources("bz_mcts.hip", tmp_path)
+    step = _find(res, "k_tree_step", "ReversiTILi8")          # cfg 3's tree step: 4+ waves per SIMD
+    assert step["vgpr"] <= 96 and step["vspill"] == 0 and step["sspill"] == 0 and step["scratch"] == 0, step
+    for gw, cap in (("ILi2E", 128), ("ILi4E", 128)):          # cfg 2's fused search (2 lanes per game is the default)
+        k = _find(res, "k_search_fused_ttt", gw)
+        assert k["vgpr"] <= cap and k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0, (gw, k)
+    play = _find(res, "k_play", "ReversiTILi8")
+    assert play["vspill"] == 0 and play["scratch"] == 0, play
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_net_kernels_do_not_spill(tmp_path):
+    res = _resources("bz_net.hip", tmp_path)
+    for parts in (("k_tower_bf16", "Li128ELi4E"), ("k_tower_bf16", "Li64ELi8E"), ("k_tower_bf16", "Li256ELi2E"),
+                  ("k_tower_bf16", "Li128ELi1E"), ("k_tower_fp8",)):
+        k = _find(res, *parts)
+        assert k["vspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
+    assert _find(res, "k_tower_fp8")["vgpr"] <= 256  # two workgroups per CU
