@@ -1153,3 +1153,34 @@ def test_net_player_follows_the_reference_aiplayer_rule():
         del g
     pl = bz.NetPlayer(1, DeviceNet.from_module(_net(128, 6, bf16=True), 4))  # the bf16 MFMA path (latency shape, B = 1)
     assert pl.get_move(bz.ReversiBoard()) in bz.ReversiBoard().generate_possible_moves(1)
+
+
+def test_gather_examples_over_rccl_world_size_1():
+    """the one collective of the multi-GPU path on the real backend ("nccl" = RCCL), as far as one GPU allows: a
+    world-size-1 process group, ONE all_gather_into_tensor of two engines' example blocks straight from the workspaces,
+    and the device-side unpack -- the pooled examples equal the engines' own."""
+    import socket
+    import torch.distributed as dist
+    from betazero_amd import distributed as bd
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        engs = [_engine("ttt", 32, 20, "hash", temp_moves=4, seed=3, game_id_base=100 * i, game_id_stride=32) for i in range(2)]
+        for e in engs:
+            e.run_iteration()
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        pooled = bd.gather_examples(engs)
+        dist.all_gather_into_tensor = real
+        assert len(calls) == 1
+        own = np.concatenate([e.examples().own for e in engs])
+        pi = np.concatenate([e.examples().pi for e in engs])
+        gid = np.concatenate([e.examples().game for e in engs])
+        assert np.array_equal(pooled.own, own) and np.array_equal(pooled.pi.view(np.uint32), pi.view(np.uint32))
+        assert np.array_equal(pooled.game, gid) and len(pooled) > 300
+    finally:
+        dist.destroy_process_group()
+        for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            os.environ.pop(k, None)
