@@ -41,6 +41,16 @@ if has pmc_env; then
   run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_env_fetch" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_fetch.txt" 2>&1
   run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_env_write" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_write.txt" 2>&1
 fi
+if has pmc_tree; then
+  # cfg 3's tree step (hidden behind the net in the bench): a short single-pipeline run, counters per launch
+  run 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d "$OUT/pmc_tree_sq" -o t -- python3 bench.py --steps 1 --warmup 0 --sims 200 --streams 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_tree_sq.json" 2> "$OUT/pmc_tree_sq.err"
+  run 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tree_tcc" -o t -- python3 bench.py --steps 1 --warmup 0 --sims 200 --streams 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_tree_tcc.json" 2> "$OUT/pmc_tree_tcc.err"
+  run 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_tree_fetch" -o t -- python3 bench.py --steps 1 --warmup 0 --sims 200 --streams 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_tree_fetch.json" 2> "$OUT/pmc_tree_fetch.err"
+  run 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_tree_write" -o t -- python3 bench.py --steps 1 --warmup 0 --sims 200 --streams 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_tree_write.json" 2> "$OUT/pmc_tree_write.err"
+fi
+if has pmc_fp8; then
+  run 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d "$OUT/pmc_fp8_sq" -o t -- python3 tools/bench_net.py 8192 60 fp8 > "$OUT/pmc_fp8_sq.txt" 2>&1
+fi
 if has clock; then
   # in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz) and per-phase stamps of the fused net kernel
   run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16.txt" 2>&1
