@@ -231,6 +231,9 @@ template <int C_, int P_ = 512 / C_> struct Tw {
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
+#if defined(BZ_EXP_NOPS) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
+#endif
 #ifdef BZ_EXP_STAMPS
 __device__ unsigned long long g_dbg[8 * 4096];
 #define BZ_STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
@@ -272,7 +275,13 @@ __device__ __forceinline__ void mfma8(f32x16 (&acc)[G::MW][G::PW][2], const bf16
         for (int p = 0; p < G::PW; ++p)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
+            {
                 acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[p][nt], acc[mt][p][nt], 0, 0, 0);
+#ifdef BZ_EXP_NOPS  // diagnostic duty sweep (tools/exp_duty_sweep.sh): BZ_EXP_NOPS x 8 idle issue cycles behind every MFMA
+#pragma unroll
+                for (int z = 0; z < BZ_EXP_NOPS; ++z) asm volatile("s_nop 7");
+#endif
+            }
 }
 
 // One weight chunk = KS k-steps of 8 MFMAs (a whole conv tap at C <= 128, half a tap at C = 256).  The chunk's weight

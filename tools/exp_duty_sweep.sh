@@ -1,0 +1,14 @@
+#!/bin/bash
+# Duty sweep of the fused bf16 net kernel: the same kernel with 0 / 1 / 2 / 4 x 8 idle issue cycles behind every MFMA
+# (diagnostic variants libbz_hip.duty<N>.so with in-kernel stamps; the product library is not touched).  If the chip is
+# holding its clock down under the MFMA load, the in-kernel clock must RISE as the duty falls and the time per forward
+# must grow by less than the added cycles.  Prints, per variant: cycles per layer, in-kernel clock, WG duration.
+set -e
+cd "$(dirname "$0")/.."
+for n in 0 1 2 4; do
+  if [ "$n" = 0 ]; then FL="['-DBZ_EXP_STAMPS']"; else FL="['-DBZ_EXP_STAMPS', '-DBZ_EXP_NOPS=$n']"; fi
+  SO=$(python -c "from betazero_amd import build; print(build.build_variant('duty$n', $FL))")
+  echo "== BZ_EXP_NOPS=$n ($((8*n)) idle cycles per MFMA)"
+  BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 python tools/exp_stamps.py | grep -v amdgpu.ids
+  BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 python tools/bench_net.py 4096 200 | grep tower
+done

@@ -10,7 +10,7 @@ x = rng.integers(0, 2**63, size=B, dtype=np.int64); y = rng.integers(0, 2**63, s
 own = torch.as_tensor(x & ~y).cuda(); opp = torch.as_tensor(y & ~x).cuda()
 torch.manual_seed(0)
 net = DeviceNet.from_module(PolicyValueNet(128, 6, 64).round_to_bf16_(), B)
-for _ in range(20): net.forward(own, opp, fp8=FP8)
+for _ in range(int(os.environ.get("WARM", "3000"))): net.forward(own, opp, fp8=FP8)  # >= 2 s of back-to-back launches before the stamps are read (DVFS settles)
 torch.cuda.synchronize()
 L = C.CDLL(_lib.SO)
 nb = 1024 if os.environ.get("NB_WG") is None else int(os.environ["NB_WG"])
