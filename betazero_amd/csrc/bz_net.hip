@@ -231,7 +231,7 @@ template <int C_, int P_ = 512 / C_> struct Tw {
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
-#if defined(BZ_EXP_NOPS) && !defined(BZ_EXPERIMENT)
+#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
 #ifdef BZ_EXP_STAMPS
@@ -280,6 +280,10 @@ __device__ __forceinline__ void mfma8(f32x16 (&acc)[G::MW][G::PW][2], const bf16
 #ifdef BZ_EXP_NOPS  // diagnostic duty sweep (tools/exp_duty_sweep.sh): BZ_EXP_NOPS x 8 idle issue cycles behind every MFMA
 #pragma unroll
                 for (int z = 0; z < BZ_EXP_NOPS; ++z) asm volatile("s_nop 7");
+#endif
+#ifdef BZ_EXP_NOP1  // finer steps: BZ_EXP_NOP1 x 1 idle issue cycle
+#pragma unroll
+                for (int z = 0; z < BZ_EXP_NOP1; ++z) asm volatile("s_nop 0");
 #endif
             }
 }

@@ -5,10 +5,14 @@
 # must grow by less than the added cycles.  Prints, per variant: cycles per layer, in-kernel clock, WG duration.
 set -e
 cd "$(dirname "$0")/.."
-for n in 0 1 2 4; do
-  if [ "$n" = 0 ]; then FL="['-DBZ_EXP_STAMPS']"; else FL="['-DBZ_EXP_STAMPS', '-DBZ_EXP_NOPS=$n']"; fi
+for n in ${SWEEP:-0 f1 f2 f4 1 2 4}; do
+  case "$n" in
+    0) FL="['-DBZ_EXP_STAMPS']";;
+    f*) FL="['-DBZ_EXP_STAMPS', '-DBZ_EXP_NOP1=${n#f}']";;      # fine steps: s_nop 0 x k
+    *) FL="['-DBZ_EXP_STAMPS', '-DBZ_EXP_NOPS=$n']";;           # coarse steps: s_nop 7 x k
+  esac
   SO=$(python -c "from betazero_amd import build; print(build.build_variant('duty$n', $FL))")
-  echo "== BZ_EXP_NOPS=$n ($((8*n)) idle cycles per MFMA)"
+  echo "== variant $n"
   BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 python tools/exp_stamps.py | grep -v amdgpu.ids
   BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 python tools/bench_net.py 4096 200 | grep tower
 done
