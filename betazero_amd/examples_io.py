@@ -48,3 +48,19 @@ def load_csv(filename):
         elif name == "Z":
             cols[name] = np.array([int(r[j]) for r in rows], dtype=np.int8)
     return cols
+
+
+def collect_game_data(num_games, player1, player2):
+    """The reference's data generator (SL/generate_training_games.py:25-38): num_games head-less tic-tac-toe games between
+    two players, every position canonicalised for its mover, the move as a one-hot "action".  Returns (states, actions)
+    as int64 arrays [n, 3, 3]; save_to_csv() then writes the reference's file.  With the reference's default players --
+    OptimalPlayer(1) vs OptimalPlayer(-1), here betazero_amd.OptimalPlayer on the library's minimax -- and the same
+    `random` seed this reproduces the reference's games move for move (the only randomness is the opening move)."""
+    from .tic_tac_toe import TicTacToeHeadless, process_game_positions
+    all_states, all_actions = [], []
+    for _ in range(num_games):
+        raw_positions, _ = TicTacToeHeadless(player1, player2).play()
+        states, actions = process_game_positions(raw_positions)
+        all_states.extend(np.asarray(states))
+        all_actions.extend(np.asarray(actions))
+    return np.array(all_states, dtype=np.int64), np.array(all_actions, dtype=np.int64)

@@ -91,3 +91,48 @@ def test_reference_reversi_minimax_player_over_our_board(monkeypatch):
             cur = -cur
         out.append((moves, np.asarray(b.board).tolist()))
     assert out[0] == out[1]
+
+
+def test_collect_game_data_reproduces_the_reference_generator(monkeypatch, tmp_path):
+    """SL/generate_training_games.py end to end: the reference's collect_game_data loop with the REFERENCE's OptimalPlayer
+    over the reference's board (its script cannot be imported -- tkinter -- so its 12-line loop body is driven here with
+    its own classes) against betazero_amd.examples_io.collect_game_data with OUR OptimalPlayer, same `random` seed:
+    identical states and actions, and an identical CSV, in the format of the reference's own tic_tac_toe_data.csv."""
+    import importlib.util
+    from betazero_amd.examples_io import collect_game_data, save_to_csv
+    path = os.path.join(REF, "src/tic_tac_toe")
+    monkeypatch.syspath_prepend(path)
+    for k in ("players", "tic_tac_toe_board"):
+        monkeypatch.delitem(sys.modules, k, raising=False)
+    spec = importlib.util.spec_from_file_location("ref_ttt_players", os.path.join(path, "players.py"))
+    rp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rp)
+    ref_board = importlib.import_module("tic_tac_toe_board").TicTacToeBoard
+
+    def ref_games(n):  # tic_tac_toe.py:13-34 + generate_training_games.py:12-23, over the reference's classes
+        p1, p2 = rp.OptimalPlayer(1), rp.OptimalPlayer(-1)
+        states, actions = [], []
+        for _ in range(n):
+            b, cur, positions = ref_board(), 1, []
+            while True:
+                positions.append(b.board)
+                r, c = (p1 if cur == 1 else p2).get_move(b)
+                b = b.make_move(r, c, cur)
+                over, _w = b.is_game_over()
+                if over:
+                    positions.append(b.board)
+                    break
+                cur = -cur
+            pos = np.stack(positions).astype(np.int64)
+            pos = pos * ((-1) ** np.arange(len(pos)))[:, None, None]
+            states.extend(pos[:-1]); actions.extend(-pos[1:] - pos[:-1])
+        return np.array(states), np.array(actions)
+
+    random.seed(2024)
+    rs, ra = ref_games(12)
+    random.seed(2024)
+    s, a = collect_game_data(12, bz.OptimalPlayer(1), bz.OptimalPlayer(-1))
+    assert np.array_equal(s, rs) and np.array_equal(a, ra) and len(s) == 12 * 9
+    f1, f2 = tmp_path / "ours.csv", tmp_path / "ref.csv"
+    save_to_csv(s, a, str(f1)); save_to_csv(rs, ra, str(f2))
+    assert f1.read_bytes() == f2.read_bytes() and f1.read_text().startswith("State,Action\n")
