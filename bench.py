@@ -581,6 +581,8 @@ def main():
                     help="reversi: steady = one move per step on a staggered pool (default); iteration = a step is a\n"
                          "complete self-play iteration from the start position to the last finished game (cross-check)")
     ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --games per GPU (default, the headline); strong = --games in total, split over the ranks")
     ap.add_argument("--reuse-subtree", action="store_true", help="supplementary: keep the chosen child's subtree (DESIGN 3.10)")
     ap.add_argument("--dirichlet-eps", type=float, default=0.0, help="supplementary: root noise weight (alpha 0.5; DESIGN 3.9)")
     args = ap.parse_args()
@@ -644,8 +646,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline_ttt(sims)
     else:
         sims = args.sims or 800
-        out = run_reversi(ctx, args, args.games or 4096, sims, args.steps if args.steps is not None else 8,
+        games = args.games or 4096
+        if args.scaling == "strong":
+            assert games % ctx.world == 0, "--scaling strong: --games must divide by the number of ranks"
+            games //= ctx.world
+        out = run_reversi(ctx, args, games, sims, args.steps if args.steps is not None else 8,
                           args.warmup if args.warmup is not None else 1)
+        if out is not None:
+            out["scaling"] = args.scaling
         if ctx.rank == 0 and ctx.world == 1:
             if not args.no_secondary:  # cfg 2 and cfg 5 in the same driver-timed process (a few seconds)
                 sec = {}
