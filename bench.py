@@ -659,7 +659,7 @@ def main():
                 sec = {}
                 for name, fn in (("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
                                  ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
-                                 ("env_step", lambda: run_env(ctx, 1 << 25, 20, 3))):
+                                 ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3))):
                     try:
                         note(f"secondary {name}")
                         r = fn()
