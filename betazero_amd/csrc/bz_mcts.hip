@@ -1068,7 +1068,9 @@ BZ_EXPORT int32_t bz_engine_evaluate(bz_engine* e, void* stream) {
     }
     if (ek == BZ_EVAL_EXTERNAL) return BZ_OK;
     BZ_REQUIRE(e->net, "bz_engine_evaluate: eval_kind needs a net (bz_engine_set_net)");
-    BZ_REQUIRE(e->cfg.game == BZ_GAME_REVERSI, "bz_engine_evaluate: the conv net is 8x8 Reversi only");
+    // the net works on 8x8 planes; the reference's 6x6 / 4x4 boards live in their top-left corner (bit = 8*row+col for
+    // every size), cells outside are never stones and never legal, so the same net serves them
+    BZ_REQUIRE(e->cfg.game != BZ_GAME_TTT, "bz_engine_evaluate: the conv net serves the Reversi boards, not tic-tac-toe");
     // leaves were packed by select: evaluate only the first flags[NEVAL] slots (device-side count)
     return bz_net_forward_dev(e->net, ek == BZ_EVAL_NET_BF16 ? 1 : (ek == BZ_EVAL_NET_FP8 ? 2 : 0), e->dev.c_own, e->dev.c_opp, e->dev.B,
                               e->dev.flags + FLAG_NEVAL + e->pack_parity, e->dev.logits, e->dev.value, stream);

@@ -117,7 +117,8 @@ class ReversiOptimalPlayer(ReversiPlayer):
 
 
 class NetPlayer(ReversiPlayer):
-    """The net-only player: AIPlayer.get_move (src/tic_tac_toe/players.py:84-98) for 8x8 Reversi and the conv
+    """The net-only player: AIPlayer.get_move (src/tic_tac_toe/players.py:84-98) for Reversi (8x8, or the reference's
+    6x6 / 4x4 boards in the top-left corner of the 8x8 planes) and the conv
     policy/value net -- canonicalise the position for the side to move (:85), one forward (:86), play the best LEGAL
     move in descending-logit order (:92-98; ties -> lowest action, where torch.sort leaves them unspecified)."""
 
@@ -127,8 +128,6 @@ class NetPlayer(ReversiPlayer):
 
     def get_move(self, board):
         import torch
-        if getattr(board, "size", 8) != 8:
-            raise ValueError("the conv net serves 8x8 Reversi only")
         own, opp = board.bits(self.symbol)
         o = torch.as_tensor(np.array([own], dtype=np.uint64).view(np.int64)).to(self.net.device)
         p = torch.as_tensor(np.array([opp], dtype=np.uint64).view(np.int64)).to(self.net.device)
@@ -147,7 +146,7 @@ class MCTSPlayer(Player):
     """get_move(board) -> (row, col) by one GPU search (PUCT, `sims` simulations)
     from `board` with `symbol` to move; plays argmax visit count (ties -> lowest
     action).  Works for TicTacToeBoard and 8x8 ReversiBoard; evaluator "net_bf16"
-    / "net_f32" need a betazero_amd.net.DeviceNet (Reversi)."""
+    / "net_f32" need a betazero_amd.net.DeviceNet (Reversi, any of the reference's board sizes)."""
 
     def __init__(self, symbol, sims=800, net=None, evaluator=None, c_puct=1.5, device="cuda:0"):
         self.symbol, self.sims, self.net, self.c_puct, self.device = symbol, sims, net, c_puct, device
@@ -164,8 +163,8 @@ class MCTSPlayer(Player):
 
     def get_move(self, board):
         game = {8: "reversi", 6: "reversi6", 4: "reversi4"}[board.size] if hasattr(board, "size") else "ttt"
-        if game != "reversi" and self.evaluator.startswith("net"):
-            raise ValueError("the conv net evaluators serve 8x8 Reversi only; use evaluator='uniform' or 'hash'")
+        if game == "ttt" and self.evaluator.startswith("net"):
+            raise ValueError("the conv net evaluators serve the Reversi boards; use evaluator='uniform' or 'hash' for tic-tac-toe")
         own, opp = board.bits(self.symbol)
         eng = self._engine(game)
         eng.set_roots([own], [opp], [self.symbol])

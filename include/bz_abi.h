@@ -36,8 +36,8 @@ extern "C" {
 
 enum { BZ_OK = 0, BZ_EINVAL = 1, BZ_EILLEGAL_MOVE = 2, BZ_EHIP = 3, BZ_ENOMEM = 4, BZ_ENOGPU = 5,
        BZ_ESTATE = 6 };
-/* REVERSI = 8x8 (the benchmark game, the only one the conv net serves); REVERSI6 / REVERSI4 = the
- * reference's 6x6 and 4x4 demo boards (same bit = 8*row+col, same 65 actions) */
+/* REVERSI = 8x8 (the benchmark game); REVERSI6 / REVERSI4 = the reference's 6x6 and 4x4 demo boards (same
+ * bit = 8*row+col, same 65 actions; the conv net serves them through the top-left corner of its 8x8 planes) */
 enum { BZ_GAME_TTT = 0, BZ_GAME_REVERSI = 1, BZ_GAME_REVERSI6 = 2, BZ_GAME_REVERSI4 = 3 };
 /* leaf evaluators: uniform priors + v=0 (BASELINE cfg 2), synthetic hash (P,v)
  * (tree-kernel parity runs), the conv net in exact-fp32 parity mode, the conv

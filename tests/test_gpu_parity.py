@@ -1184,3 +1184,31 @@ def test_gather_examples_over_rccl_world_size_1():
         dist.destroy_process_group()
         for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             os.environ.pop(k, None)
+
+
+def test_net_evaluators_serve_the_small_reversi_boards():
+    """the reference plays Reversi on 6x6 (its GUI) and 4x4 (its demo) too: those boards sit in the top-left corner of the
+    net's 8x8 planes, so the same net serves them -- self-play with the exact-fp32 net in the loop is bit-exact vs the
+    oracle on both sizes, the bf16 MFMA net plays legal games, and MCTSPlayer / NetPlayer accept the boards."""
+    import betazero_amd as bz
+    from betazero_amd.net import DeviceNet
+    m = _net(32, 2, seed=6)
+    dn, on = DeviceNet.from_module(m, 8), orc.Net(32, 2, 64, m.flat_params())
+    for game, og, size in (("reversi6", orc.GAME_REVERSI6, 6), ("reversi4", orc.GAME_REVERSI4, 4)):
+        eng = _engine(game, 6, 14, "net_f32", net=dn, temp_moves=4, seed=5, game_id_base=20)
+        eng.run_iteration()
+        ex = eng.examples()
+        winners, lens = eng.winners()
+        for g in range(6):
+            r = orc.selfplay_game(og, 20 + g, 14, orc.EVAL_NET_F32, 4, 0, 5, net=on)
+            mk = ex.game == 20 + g
+            assert lens[0, g] == len(r["own"]) and winners[0, g] == r["winner"]
+            assert np.array_equal(ex.act[mk], r["act"]) and np.array_equal(ex.pi[mk].view(np.uint32), r["pi"].view(np.uint32))
+        assert ((ex.own | ex.opp) & ~np.uint64(sum(((1 << size) - 1) << (8 * r_) for r_ in range(size)))).max() == 0
+    big = DeviceNet.from_module(_net(128, 6, bf16=True), 8)
+    eng = _engine("reversi6", 8, 16, "net_bf16", net=big, temp_moves=4)
+    eng.run_iteration()
+    assert (eng.winners()[1][0] >= 5).all()
+    b6 = bz.ReversiBoard(size=6)
+    assert bz.MCTSPlayer(1, sims=20, net=big).get_move(b6) in b6.generate_possible_moves(1)
+    assert bz.NetPlayer(1, big).get_move(b6) in b6.generate_possible_moves(1)
