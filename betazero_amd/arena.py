@@ -38,8 +38,7 @@ class ArenaResult:
 def play_arena(game, n_games, sims, opponent_depth=4, evaluator="uniform", net=None, c_puct=1.5, seed=0, size=8,
                device="cuda:0", max_plies=200):
     """MCTS (`sims` simulations, `evaluator`) vs minimax for n_games concurrent games; the MCTS side plays X
-    (moves first) in the even-numbered games and O in the odd ones.  game: "ttt" | "reversi" (size 8, or 6 / 4 with the
-    uniform or hash evaluator)."""
+    (moves first) in the even-numbered games and O in the odd ones.  game: "ttt" | "reversi" (size 8, 6 or 4)."""
     _lib.require_gpu()
     L = _lib.lib()
     dev = torch.device(device)
