@@ -108,6 +108,22 @@ class SelfPlayEngine:
     def search(self):
         self._call(_lib.lib().bz_engine_search)
 
+    def search_external(self, eval_fn):
+        """One full search with a caller-supplied evaluator (engine built with evaluator="external"): eval_fn(own, opp,
+        kind) gets the leaf positions as int64 CUDA tensors [B] (uint64 bit patterns, side-to-move canonical -- the input
+        convention of the reference's AIPlayer, players.py:85) and kind (uint8 [B], 1 = needs evaluation) and returns
+        (logits [B, NA] float32, value [B] float32) CUDA tensors; legality masking and the softmax happen in the expansion.
+        Any torch module can sit here -- e.g. an MLP over the 9 tic-tac-toe cells like the reference's TicTacToeNet."""
+        lb = self.leaf_buffers()
+
+        def fill():
+            lg, v = eval_fn(lb["own"], lb["opp"], lb["kind"])
+            lb["logits"].copy_(lg.to(torch.float32).reshape(lb["logits"].shape))
+            lb["value"].copy_(v.to(torch.float32).reshape(lb["value"].shape))
+        self.root_begin(); fill(); self.expand_backup()
+        for s in range(self.sims):
+            self.select(s); fill(); self.expand_backup()
+
     def root_begin(self):
         self._call(_lib.lib().bz_engine_root_begin)
 

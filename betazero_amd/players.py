@@ -150,6 +150,11 @@ class MCTSPlayer(Player):
 
     def __init__(self, symbol, sims=800, net=None, evaluator=None, c_puct=1.5, device="cuda:0"):
         self.symbol, self.sims, self.net, self.c_puct, self.device = symbol, sims, net, c_puct, device
+        # evaluator: "uniform" | "hash" | "net_bf16" | "net_f32" | "net_fp8", or a callable (own, opp, kind) -> (logits, value)
+        # on CUDA tensors (SelfPlayEngine.search_external): any torch module, e.g. an MLP for tic-tac-toe
+        self.eval_fn = evaluator if callable(evaluator) else None
+        if self.eval_fn is not None:
+            evaluator = "external"
         self.evaluator = evaluator or ("net_bf16" if net is not None else "uniform")
         self._eng = {}
         self.last_visits = None
@@ -168,7 +173,10 @@ class MCTSPlayer(Player):
         own, opp = board.bits(self.symbol)
         eng = self._engine(game)
         eng.set_roots([own], [opp], [self.symbol])
-        eng.search()
+        if self.eval_fn is not None:
+            eng.search_external(self.eval_fn)
+        else:
+            eng.search()
         N, _, _ = eng.root_stats()
         eng.status()  # raises on engine error flags (e.g. terminal root)
         self.last_visits = N[0]

@@ -1212,3 +1212,44 @@ def test_net_evaluators_serve_the_small_reversi_boards():
     b6 = bz.ReversiBoard(size=6)
     assert bz.MCTSPlayer(1, sims=20, net=big).get_move(b6) in b6.generate_possible_moves(1)
     assert bz.NetPlayer(1, big).get_move(b6) in b6.generate_possible_moves(1)
+
+
+def test_external_torch_evaluator_in_the_search():
+    """SelfPlayEngine.search_external / MCTSPlayer(evaluator=callable): any torch module as the leaf evaluator.  (1) a
+    callable that reproduces the synthetic hash evaluator gives the fused kernel's root statistics bit for bit; (2) a torch
+    MLP over the 9 tic-tac-toe cells (the shape of the reference's TicTacToeNet, SL/neural_networks.py) drives legal games
+    through the reference-style loop."""
+    import random
+    import betazero_amd as bz
+    d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
+    live = d["pos"][d["pos"][:, 4] == 0][:64]
+    tm = np.where(live[:, 2] == 1, 1, -1).astype(np.int8)
+    own = np.where(tm == 1, live[:, 0], live[:, 1]).astype(np.uint64)
+    opp = np.where(tm == 1, live[:, 1], live[:, 0]).astype(np.uint64)
+
+    def hash_fn(o, p, kind):
+        oc, pc = o.cpu().numpy().view(np.uint64), p.cpu().numpy().view(np.uint64)
+        lg, v = np.zeros((len(oc), 9), np.float32), np.zeros(len(oc), np.float32)
+        for i in range(len(oc)):
+            lg[i], v[i] = orc.eval_hash(int(oc[i]), int(pc[i]), 9)
+        return torch.from_numpy(lg).to(DEV), torch.from_numpy(v).to(DEV)
+    e1, e2 = _engine("ttt", 64, 30, "external"), _engine("ttt", 64, 30, "hash")
+    for e in (e1, e2):
+        e.set_roots(own, opp, tm)
+    e1.search_external(hash_fn)
+    e2.search()
+    a, b = e1.root_stats(), e2.root_stats()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(9, 32), torch.nn.ReLU(), torch.nn.Linear(32, 10)).to(DEV)
+
+    def mlp_fn(o, p, kind):
+        sh = torch.arange(9, device=DEV)
+        x = ((o[:, None] >> sh) & 1).float() - ((p[:, None] >> sh) & 1).float()  # canonical: +1 = side to move
+        with torch.no_grad():
+            y = mlp(x)
+        return y[:, :9], torch.tanh(y[:, 9])
+    random.seed(1)
+    pl = bz.MCTSPlayer(1, sims=40, evaluator=mlp_fn)
+    positions, winner = bz.TicTacToeHeadless(pl, bz.RandomPlayer()).play()
+    assert winner in (1, 0, -1) and 6 <= len(positions) <= 10
