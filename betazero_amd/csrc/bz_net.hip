@@ -214,6 +214,11 @@ template <int C_, int P_ = 512 / C_> struct Tw {
     static constexpr int KS = KC < 8 ? KC : 8;         // k-steps per weight-prefetch chunk (register set)
     static constexpr int CPT = KC / KS;                // chunks per tap
     static constexpr int NCH = 9 * CPT;                // chunks per layer
+    // register sets of weight fragments = how far ahead the weight stream is fetched (DEPTH - 1 chunks).  The
+    // throughput shapes issue 8 MFMAs per k-step, so one chunk ahead is 2048+ cycles -- beyond the L2 latency; the
+    // latency shapes issue 2, one chunk is only ~512 cycles, so they fetch two chunks ahead (three sets)
+    static constexpr int DEPTH = MW * PW <= 2 ? 3 : 2;
+    static_assert((2 * NCH) % DEPTH == 0, "a residual block must bring the register-set rotation back to set 0");
     static __device__ __forceinline__ int wt0(int w) { return (w % NG) * MW; }
     static __device__ __forceinline__ int pos0(int w) { return (w / NG) * PW; }
     // XOR swizzle of the 16-byte chunk index inside a cell, chosen so that the 16 lanes of every ds_read_b128 lane
@@ -289,17 +294,18 @@ __device__ __forceinline__ void mfma8(f32x16 (&acc)[G::MW][G::PW][2], const bf16
 }
 
 // One weight chunk = KS k-steps of 8 MFMAs (a whole conv tap at C <= 128, half a tap at C = 256).  The chunk's weight
-// fragments are in register set S (A0 or A1); the other set is filled for the next chunk (coalesced 1 KB loads, a
-// whole chunk ahead; the fragment stream is linear over chunks, taps and layers).  Activation fragments are double-
+// fragments are in register set S of DEPTH; the set freed by the previous chunk is filled for the chunk DEPTH - 1
+// ahead (coalesced 1 KB loads; the fragment stream is linear over chunks, taps and layers).  Activation fragments are double-
 // buffered (b0/b1): the ds_read_b128 of k-step k+1 are issued between the MFMAs of k-step k.  `in` points at the wave's
 // first position; (boff, kc0) address this chunk, (tap_n, kc0_n) the next one.
+template <class G> struct WSets { bf16x8 s[G::DEPTH][G::KS][G::MW]; };  // the weight-fragment register sets
+
 template <int S, class G>
-__device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::PW][2], bf16x8 (&A0)[G::KS][G::MW],
-                                           bf16x8 (&A1)[G::KS][G::MW], const uint4*& ap, const char* in,
+__device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::PW][2], WSets<G>& WS, const uint4*& ap, const char* in,
                                            int (&boff)[2], int kc0, int tap_n, int kc0_n, int r, int h,
                                            bf16x8 (&b0)[G::PW][2], bf16x8 (&b1)[G::PW][2]) {
-    bf16x8 (&use)[G::KS][G::MW] = S ? A1 : A0;
-    bf16x8 (&nxt)[G::KS][G::MW] = S ? A0 : A1;
+    bf16x8 (&use)[G::KS][G::MW] = WS.s[S];
+    bf16x8 (&nxt)[G::KS][G::MW] = WS.s[(S + G::DEPTH - 1) % G::DEPTH];  // the set the previous chunk has just freed
 #pragma unroll
     for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
@@ -371,11 +377,11 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::PW][2], char* o
 }
 
 // One conv3x3 layer over the resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
-// S0 = register set that holds chunk 0's weight fragments on entry; on exit it is set S0 ^ (NCH & 1).
+// S0 = register set that holds chunk 0's weight fragments on entry; on exit it is set (S0 + NCH) % DEPTH.
 template <int S0, class G>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
-                                           bf16x8 (&A0)[G::KS][G::MW], bf16x8 (&A1)[G::KS][G::MW],
-                                           const uint4*& ap, int w, int r, int h, unsigned long long (&tacc)[4]) {
+                                           WSets<G>& WS, const uint4*& ap, int w, int r, int h,
+                                           unsigned long long (&tacc)[4]) {
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
     f32x16 acc[G::MW][G::PW][2];
@@ -392,13 +398,17 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     // chunk c covers tap c / CPT, k-steps (c % CPT) * KS ..; the chunk after the last one is a harmless re-read
     auto tap_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return c / G::CPT; };
     auto kc0_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return (c % G::CPT) * G::KS; };
+    constexpr int D = G::DEPTH, R = G::NCH % D, C0 = G::NCH - R;
+#define BZ_CHUNK(J, CC) chunk_step<(S0 + (J)) % D, G>(acc, WS, ap, in, boff, kc0_of(CC), tap_of((CC) + 1), kc0_of((CC) + 1), r, h, b0, b1)
 #pragma unroll 1
-    for (int c = 0; c + 1 < G::NCH; c += 2) {
-        chunk_step<S0, G>(acc, A0, A1, ap, in, boff, kc0_of(c), tap_of(c + 1), kc0_of(c + 1), r, h, b0, b1);
-        chunk_step<1 - S0, G>(acc, A0, A1, ap, in, boff, kc0_of(c + 1), tap_of(c + 2), kc0_of(c + 2), r, h, b0, b1);
+    for (int c = 0; c + D <= G::NCH; c += D) {  // the register-set index must be a compile-time constant: unroll by DEPTH
+        BZ_CHUNK(0, c);
+        BZ_CHUNK(1, c + 1);
+        if constexpr (D >= 3) BZ_CHUNK(2, c + 2);
     }
-    if (G::NCH & 1)
-        chunk_step<S0, G>(acc, A0, A1, ap, in, boff, kc0_of(G::NCH - 1), tap_of(G::NCH), kc0_of(G::NCH), r, h, b0, b1);
+    if constexpr (R >= 1) BZ_CHUNK(C0, C0);
+    if constexpr (R >= 2) BZ_CHUNK(C0 + 1, C0 + 1);
+#undef BZ_CHUNK
     BZ_STAMP(t1);
     epilogue<G>(acc, out, second, bl, G::wt0(w), r, h);
     BZ_STAMP(t2);
@@ -483,12 +493,15 @@ k_tower_bf16(TowerArgs T) {
     // weight-fragment stream of this wave: k-step ks, M-tile mt -> wf[(ks * MT + mt) * 64 + lane], linear over layers
     const int wt0 = G::wt0(w), wp0 = G::pos0(w);
     const uint4* ap = T.wf + (size_t)wt0 * 64 + lane;
-    bf16x8 A0[G::KS][MW], A1[G::KS][MW];
+    WSets<G> WS;
 #pragma unroll
-    for (int kc = 0; kc < G::KS; ++kc)
+    for (int d = 0; d + 1 < G::DEPTH; ++d) {  // chunks 0 .. DEPTH - 2 of the first layer
 #pragma unroll
-        for (int mt = 0; mt < MW; ++mt) A0[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
-    ap += G::KS * G::MT * 64;
+        for (int kc = 0; kc < G::KS; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+        ap += G::KS * G::MT * 64;
+    }
 
     // ---- stem: conv3x3 2 -> C as a [C x 32] x [32 x 64] GEMM per position
     {
@@ -523,8 +536,8 @@ k_tower_bf16(TowerArgs T) {
     // ---- tower: a residual block = conv1 (X -> M) + conv2 (M -> X in place, + skip X)
 #pragma unroll 1
     for (int blk = 0; blk < T.n_layers / 2; ++blk) {
-        conv_layer<0, G>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * C, A0, A1, ap, w, r, h, tacc);
-        conv_layer<(G::NCH & 1), G>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * C, A0, A1, ap, w, r, h, tacc);
+        conv_layer<0, G>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * C, WS, ap, w, r, h, tacc);
+        conv_layer<G::NCH % G::DEPTH, G>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * C, WS, ap, w, r, h, tacc);
     }
     BZ_STAMP(tk1);
 
@@ -886,7 +899,7 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     o.conv_w = k.take(L * 9 * C * C * 4); o.conv_b = k.take(L * C * 4);
     const bool mfma = C == 64 || C == 128 || C == 256;  // widths the fused bf16 MFMA kernel is built for
     const int64_t KC = C / 16, MT = C / 32;             // k-steps per tap, M-tiles (1-KB fragments: [kc][mt][64 lanes][8])
-    o.conv_wf = k.take(mfma ? (L * 9 + 1) * KC * MT * 1024 : 0);
+    o.conv_wf = k.take(mfma ? (L * 9 + 2) * KC * MT * 1024 : 0);  // + 2 taps: the prefetch runs up to two chunks past the end
     o.stem_wf = k.take(mfma ? 2 * MT * 1024 : 0); o.head_wf = k.take(mfma ? KC * 1024 : 0);
     o.conv_wf8 = k.take(C == kTC ? (L * 9 + 1) * 2LL * 4 * 2 * 64 * 16 : 0); o.head_wf8 = k.take(2 * 2 * 64 * 16);
     o.dq8 = k.take((L + 1) * 128 * 4); o.head_dq8 = k.take(16); o.ones = k.take(128 * 4);
