@@ -458,15 +458,20 @@ def run_reversi(ctx, args, B, sims, K, W):
         e.reset_counters()
     L.bz_profile_reset()
     prof_on = not args.no_kernel_timers
-    if prof_on and args.mode == "steady":  # events exist before the timed loop: it only records them
-        per = K * NS * (sims + 2) + 64
+    PROF_CAP = 1 << 18                      # launches a timer slot holds (bz_abi.h)
+    prof_steps = K                          # steps whose launches carry timers: all of them unless a soak run overflows the slots
+    if prof_on and args.mode == "steady":   # events exist before the timed loop: it only records them
+        prof_steps = max(1, min(K, (PROF_CAP - 64) // (NS * (sims + 2))))
+        per = prof_steps * NS * (sims + 2) + 64
         for slot in ("tower", "select", "expand_backup", "play"):
             L.bz_profile_reserve(_lib.PROF_SLOTS.index(slot), per)
     L.bz_profile_enable(1 if prof_on else 0)
     ctx.barrier()
     note(f"timed region: {K} steps")
     t0 = time.perf_counter()
-    for _ in range(K):
+    for i in range(K):
+        if i == prof_steps and prof_on:
+            L.bz_profile_enable(0)          # (a relaxed atomic store: no synchronisation, nothing waits)
         step()
     ctx.sync()
     pooled_bytes = 0
@@ -516,14 +521,18 @@ def run_reversi(ctx, args, B, sims, K, W):
         note("kernel timers read")
         launches, timed, ms = prof["tower"]
         assert timed == launches, f"kernel-timer capacity exceeded ({timed} of {launches} launches timed)"
-        # leaves are packed before the net runs: a launch evaluates only the non-terminal leaves
-        flop_per_launch = cnt["n_net_leaves"] / max(launches, 1) * NET_FLOP_PER_POS  # stem+tower+heads = ONE kernel
+        # leaves are packed before the net runs: a launch evaluates only the non-terminal leaves.  When only the first
+        # prof_steps steps carried timers (soak runs), positions per launch is the whole run's mean: every step of the
+        # steady-state pool issues the same NS x (sims + 1) net launches
+        all_launches = K * NS * (sims + 1) if (args.mode == "steady" and prof_steps < K) else launches
+        flop_per_launch = cnt["n_net_leaves"] / max(all_launches, 1) * NET_FLOP_PER_POS  # stem+tower+heads = ONE kernel
         union_ms, sum_ms = _lib.profile_union_ms("tower")
         ach = flop_per_launch * launches / (union_ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": None, "launches": launches, "flop_per_launch": flop_per_launch,
-            "positions_per_launch": cnt["n_net_leaves"] / max(launches, 1),
+            "positions_per_launch": flop_per_launch / NET_FLOP_PER_POS,
+            **({"timed_steps": prof_steps} if prof_steps < K else {}),
             # the NS pipelines' launches overlap on the chip, so a launch's own event-to-event duration is
             # SHARED time.  `achieved` = flop_per_launch x launches / busy_ms, busy_ms = union of all launch
             # intervals (every launch timed, nothing extrapolated); avg_launch_ms = busy_ms / launches is the
@@ -541,7 +550,7 @@ def run_reversi(ctx, args, B, sims, K, W):
                 break
             except Exception:
                 continue
-        tb = tree_bytes(cnt)
+        tb = tree_bytes(cnt) * (prof_steps / K if (args.mode == "steady" and prof_steps < K) else 1.0)  # the timed steps' share
         t_union, t_sum = _lib.profile_union_ms("select")
         out["roofline_tree"] = {"bound": "hbm", "kernels": "k_tree_step (expand + backup + select, 16 lanes per game)",
                                 "achieved": tb / (t_sum * 1e-3) / 1e9 if t_sum else None, "peak": HBM_PEAK_GBS,
