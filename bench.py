@@ -466,6 +466,12 @@ def run_reversi(ctx, args, B, sims, K, W):
         for slot in ("tower", "select", "expand_backup", "play"):
             L.bz_profile_reserve(_lib.PROF_SLOTS.index(slot), per)
     L.bz_profile_enable(1 if prof_on else 0)
+    if ctx.world > 1:  # untimed: the first all-gather of a process group sets up RCCL's channels and buffers
+        wdev = ctx.dev if ctx.backend == "nccl" else "cpu"
+        wsend = torch.zeros(1 << 20, dtype=torch.uint8, device=wdev)
+        wrecv = torch.empty(ctx.world << 20, dtype=torch.uint8, device=wdev)
+        dist.all_gather_into_tensor(wrecv, wsend)
+        del wsend, wrecv
     ctx.barrier()
     note(f"timed region: {K} steps")
     t0 = time.perf_counter()
