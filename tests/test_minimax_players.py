@@ -96,3 +96,44 @@ def test_ttt_optimal_player_class_never_loses_to_itself_and_matches_memoised_min
         if t.is_game_over()[0]:
             continue
         assert bz.OptimalPlayer(cur).get_move(t) == bz.MinimaxPlayer(cur).get_move(t)
+
+
+def _py_minimax(board, symbol, max_depth, is_max=True, depth=0):
+    """the decision rule of reversi_players.py:41-69 written over the Game API (no pass rule inside the search, -inf / +inf
+    for a side without a move, first strictly better move wins) -- an independent yard-stick for random positions"""
+    if depth >= max_depth or board.is_game_over():
+        w, (n1, n2) = board.get_score()
+        return (n1 - n2 if symbol == 1 else n2 - n1), None
+    best, best_move = (float("-inf"), None) if is_max else (float("inf"), None)
+    for mv in board.generate_possible_moves(symbol if is_max else -symbol):
+        sc, _ = _py_minimax(board.make_move(*mv, symbol if is_max else -symbol), symbol, max_depth, not is_max, depth + 1)
+        if (is_max and sc > best) or (not is_max and sc < best):
+            best, best_move = sc, mv
+    return best, best_move
+
+
+def test_reversi_minimax_random_positions_vs_game_api_restatement():
+    """260 random positions (sizes 4 / 6 / 8, depths 0-3, both colours, incl. positions where the player has no move):
+    bz_reversi_minimax == the rule restated over the API-compatible board (itself pinned to the reference by F1-F6)"""
+    rng = random.Random(11)
+    n_none = 0
+    for trial in range(260):
+        size = rng.choice((4, 4, 6, 6, 8))
+        b, cur = bz.ReversiBoard(size=size), 1
+        for _ in range(rng.randrange(0, size * size - 4)):
+            mv = b.generate_possible_moves(cur)
+            if not mv:
+                cur = -cur
+                mv = b.generate_possible_moves(cur)
+                if not mv:
+                    break
+            b = b.make_move(*rng.choice(mv), cur)
+            cur = -cur
+        sym, depth = rng.choice((1, -1)), rng.choice((0, 1, 2, 3)) if size > 4 else rng.choice((0, 1, 2, 3, 4))
+        sc, mv = _py_minimax(b, sym, depth)
+        own, opp = b.bits(sym)
+        gm, gs = _rev(own, opp, size, depth)
+        exp_sc = 1000 if sc == float("inf") else (-1000 if sc == float("-inf") else sc)
+        assert (gm, gs) == (-1 if mv is None else 8 * mv[0] + mv[1], exp_sc), (trial, size, depth, sym)
+        n_none += mv is None
+    assert n_none > 10
