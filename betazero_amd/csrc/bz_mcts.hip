@@ -9,6 +9,9 @@
 // the select path is stored depth-major path[d][g].  A simulation is two launches: k_tree_step
 // ([expand + backup of the previous leaf] + [select of the next one]) and the evaluator; leaves
 // that need the net are packed through a double-buffered device-side counter.
+// Synthetic evaluators run the whole search in one launch (k_search_fused; k_search_fused_ttt for tic-tac-toe at
+// sims <= 120: root edges in registers, child header packed into the edge word, path in LDS).  Opt-in: Dirichlet root
+// noise (k_root_noise) and subtree reuse (two arenas, dev_reroot) -- DESIGN.md 3.9, 3.10.
 //
 // Float discipline: compiled with -ffp-contract=off; PUCT / softmax / backup use
 // the single-rounding operation order of the oracle (oracle/bz_oracle.c), so
