@@ -185,15 +185,28 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
 constexpr int kTC = 128;                  // channels of the benchmark net (the fp8 tower serves only this width)
 
 // Geometry of the fused bf16 net kernel for C = 64, 128 or 256 channels.  A workgroup of 4 waves keeps P positions
-// resident in LDS and its accumulator tiles (MT M-tiles of 32 output channels x P positions x 2 cell tiles) are
-// dealt to the waves as MW M-tiles x PW positions each.
-// Throughput shape (P = 512 / C: 2 buffers x P x TILE = 133 KB of LDS for every width, one workgroup per CU):
+// resident in LDS and its accumulator tiles (MT M-tiles of 32 output channels x P positions x 64 cells) are dealt
+// to the waves as MW M-tiles x PW positions each, i.e. NU = 2 PW tiles of 32 cells ("units") per M-tile.
+// Throughput shape (P = 512 / C: 2 buffers x P x TILE = 146 KB of LDS for every width, one workgroup per CU):
 //   C =  64: P = 8, wave w -> M-tile  w & 1,        positions 4 (w >> 1) .. +3   (MW 1, PW 4)
 //   C = 128: P = 4, wave w -> M-tile  w,            positions 0 .. 3             (MW 1, PW 4)   <- the benchmark net
 //   C = 256: P = 2, wave w -> M-tiles 2w, 2w + 1,   positions 0, 1               (MW 2, PW 2)
 // Latency shape for small batches (P = 1; 2 at C = 64): one position per workgroup -- a batch of up to 256 positions
 // then spreads over as many CUs instead of 4 positions sharing one (an interactive MCTSPlayer search is B = 1: the
 // throughput shape would compute three padding positions for every real one).
+//
+// Which 32 cells make a unit (ROWT).  With four positions per wave a unit is ONE BOARD ROW of the four positions
+// (lane r -> position r >> 3, column r & 7; unit u = row u) instead of four rows of one position.  A conv tap with row
+// shift dy = -1 then reads nothing but zero padding for the whole of unit 0 (dy = +1: unit 7), and that MFMA -- and its
+// LDS read -- is skipped: 6 of the 9 taps issue 7 MFMAs per k-step instead of 8, 8.3 % of the tower's matrix work.  The
+// skipped products are exact zeros, so every output is bit-identical to the full sum.  (Padding along x cannot be
+// skipped the same way: a 32-cell unit cannot be a board column AND a board row.)  Waves with fewer than four
+// positions keep the position-major units (lane r -> row 4 nt + (r >> 3), column r & 7 of one position).
+//
+// LDS image of a position: 8 board rows at a pitch of 9 cells -- 8 squares and one all-zero cell, which is the x = 8
+// halo of its row and the x = -1 halo of the next one -- plus one leading zero cell: 73 cells.  A tap's column shift
+// is then a plain address offset for every lane (no per-lane halo test).  Rows -1 and 8 do not exist: row-tile units
+// skip them, position-major units point the affected lanes at a zero cell.
 // (Round 1 measured 2 positions x 2 workgroups per CU, a tile-major last tap and the 16x16x32 MFMA shape, round 2 the
 // MW = 2 split at C = 128: all within +-1 % because the kernel sits on the power-limited clock -- DESIGN.md 5.)
 template <int C_, int P_ = 512 / C_> struct Tw {
@@ -202,8 +215,9 @@ template <int C_, int P_ = 512 / C_> struct Tw {
     static constexpr int KC = C / 16;                  // k-steps (16 input channels) per conv tap
     static constexpr int MT = C / 32;                  // M-tiles (32 output channels)
     static constexpr int CELL = 2 * C;                 // bytes of one board cell (all channels, bf16)
-    static constexpr int ZERO = C == 64 ? 256 : CELL;  // zero region read by the conv halo (128-B cells: one per x parity)
-    static constexpr int TILE = 64 * CELL + ZERO;      // bytes of one position
+    static constexpr int ROWC = 9;                     // cells per board-row pitch: 8 squares + 1 zero cell
+    static constexpr int NCELL = 8 * ROWC + 1;         // + the zero cell in front of row 0
+    static constexpr int TILE = NCELL * CELL;          // bytes of one position
     static constexpr int P = P_;                       // positions resident per workgroup
     static constexpr int BUF = P * TILE;
     static constexpr int LDS = 2 * BUF;
@@ -211,7 +225,16 @@ template <int C_, int P_ = 512 / C_> struct Tw {
     static constexpr int PW = MT * P / 4 / MW;         // positions per wave
     static_assert(MW * PW * 4 == MT * P && PW >= 1, "the (M-tile, position) units must split evenly over 4 waves");
     static constexpr int NG = MT / MW;                 // wave groups along M
+    static constexpr int NU = 2 * PW;                  // 32-cell units per M-tile of a wave
+#ifdef BZ_EXP_NO_ROWT  // diagnostic A/B (position-major units for every shape: no skipped MFMAs)
+    static constexpr bool ROWT = false;
+#else
+    static constexpr bool ROWT = PW == 4;              // units are board rows across the wave's four positions
+#endif
     static constexpr int KS = KC < 8 ? KC : 8;         // k-steps per weight-prefetch chunk (register set)
+    // activation-fragment buffers: fetched NBUF - 1 k-steps ahead (3 buffers and 3 weight sets were A/B'd on the
+    // row-tile kernel: no change -- neither LDS nor L2 latency is what the K-loop waits for)
+    static constexpr int NBUF = 2;
     static constexpr int CPT = KC / KS;                // chunks per tap
     static constexpr int NCH = 9 * CPT;                // chunks per layer
     // register sets of weight fragments = how far ahead the weight stream is fetched (DEPTH - 1 chunks).  The
@@ -221,22 +244,40 @@ template <int C_, int P_ = 512 / C_> struct Tw {
     static_assert((2 * NCH) % DEPTH == 0, "a residual block must bring the register-set rotation back to set 0");
     static __device__ __forceinline__ int wt0(int w) { return (w % NG) * MW; }
     static __device__ __forceinline__ int pos0(int w) { return (w / NG) * PW; }
+    // byte offset of cell (y, x) inside a position, x = -1 .. 8 (the ends are zero cells)
+    static __device__ __forceinline__ constexpr int cell_at(int y, int x) { return (y * ROWC + x + 1) * CELL; }
     // XOR swizzle of the 16-byte chunk index inside a cell, chosen so that the 16 lanes of every ds_read_b128 lane
-    // group (16 different cells of a 4-row patch, any tap shift) hit 16 distinct 16-byte bank slots: 256-B and
-    // 512-B cells span whole bank rows -> 4 bits from (x, y & 1); 128-B cells share a bank row in pairs (x parity)
-    // -> 3 bits from (x >> 1, y & 1)
-    static __device__ __forceinline__ int sw(int yy, int xx) {
-        return C == 64 ? (((xx & 7) >> 1) | ((yy & 1) << 2)) : ((xx & 7) | ((yy & 1) << 3));
+    // group (8 columns x 2 values of `sel`, any tap shift) hit 16 distinct 16-byte bank slots: 256-B and 512-B cells
+    // span whole bank rows -> 4 bits from (x, sel); 128-B cells share a bank row in pairs (cell-index parity = x
+    // parity within the group) -> 3 bits from (x >> 1, sel).  sel = the other lane coordinate of a unit: the
+    // position (row-tile units) or the board row (position-major units).
+    static __device__ __forceinline__ int sw(int sel, int xx) {
+        return C == 64 ? (((xx & 7) >> 1) | ((sel & 1) << 2)) : ((xx & 7) | ((sel & 1) << 3));
     }
-    // byte offset of 16-byte chunk k of cell c inside a position tile
-    static __device__ __forceinline__ int cell_off(int c, int k) { return c * CELL + ((k ^ sw(c >> 3, c & 7)) << 4); }
+    // byte offset of 16-byte chunk k of board cell c of the workgroup's position p, inside that position
+    static __device__ __forceinline__ int cell_off(int p, int c, int k) {
+        return cell_at(c >> 3, c & 7) + ((k ^ sw(ROWT ? p : c >> 3, c & 7)) << 4);
+    }
+    // unit u, lane column r (0..31) -> position inside the wave and board cell
+    static __device__ __forceinline__ int unit_pos(int u, int r) { return ROWT ? r >> 3 : u >> 1; }
+    static __device__ __forceinline__ int unit_cell(int u, int r) { return ROWT ? 8 * u + (r & 7) : 32 * (u & 1) + r; }
+    // LDS offset of that cell = lane_home(r) + unit_imm(u): a per-lane part and a compile-time part
+    static __device__ __forceinline__ int lane_home(int r) {
+        return ROWT ? (r >> 3) * TILE + cell_at(0, r & 7) : cell_at(r >> 3, r & 7);
+    }
+    static __device__ __forceinline__ constexpr int unit_imm(int u) {
+        return ROWT ? u * ROWC * CELL : (u >> 1) * TILE + (u & 1) * 4 * ROWC * CELL;
+    }
+    // units that read at least one board row for a tap with row shift dy: [unit_lo, unit_hi)
+    static __device__ __forceinline__ constexpr int unit_lo(int dy) { return ROWT && dy < 0 ? 1 : 0; }
+    static __device__ __forceinline__ constexpr int unit_hi(int dy) { return ROWT && dy > 0 ? NU - 1 : NU; }
 };
 
 // Diagnostic build only (tools/exp_stamps.sh -> a separate libbz_hip.stamps.so, never the product .so)
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
-#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1)) && !defined(BZ_EXPERIMENT)
+#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
 #ifdef BZ_EXP_STAMPS
@@ -246,64 +287,78 @@ __device__ unsigned long long g_dbg[8 * 4096];
 #define BZ_STAMP(var) do { } while (0)
 #endif
 
-// LDS byte offsets (inside a position tile) of the B-operand chunk h of k-step 0 for conv tap `tap`, for the lane's
-// two cell tiles; load_b XORs the k-step in.
-template <class G>
-__device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        int cell = 32 * nt + r, yy = (cell >> 3) + dy, xx = (cell & 7) + dx;
-        bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
-        // out of the board -> the zero region.  The swizzle comes from the UNCLAMPED coordinates: a halo lane then
-        // reads the slot of the zero region that its virtual cell would occupy, so the 16 lanes of a ds_read_b128
-        // group still hit 16 distinct slots (no bank conflict between halo and board lanes)
-        int base = inb ? (yy * 8 + xx) * G::CELL : 64 * G::CELL + (G::C == 64 ? (xx & 1) * 128 : 0);
-        boff[nt] = base + ((G::sw(yy, xx) ^ h) << 4);
-    }
+// Per-lane LDS byte offsets of the B-operand chunk h of k-step 0 for conv tap TAP, relative to the wave's first
+// position; load_b XORs the k-step in and adds the unit's compile-time offset.
+//  * row-tile units: ONE offset (the lane's position and column x + dx; the halo columns are zero cells of the
+//    layout); the row (u + dy) is part of the compile-time offset.
+//  * position-major units: one offset per cell tile nt (rows 4 nt + (r >> 3) + dy); a lane whose row falls off the board
+//    reads a zero cell.  The swizzle always comes from the UNCLAMPED coordinates, so a halo lane reads the slot that
+//    its virtual cell would occupy and the 16 lanes of a ds_read_b128 group still hit 16 distinct slots.
+template <class G, int TAP>
+__device__ __forceinline__ void tap_off(int r, int h, int (&boff)[2]) {  // row-tile units
+    constexpr int dx = TAP % 3 - 1;
+    const int xx = (r & 7) + dx;
+    boff[0] = (r >> 3) * G::TILE + G::cell_at(0, xx) + ((G::sw(r >> 3, xx) ^ h) << 4);
+    boff[1] = 0;
 }
 template <class G>
-__device__ __forceinline__ void load_b(bf16x8 (&b)[G::PW][2], const char* in, const int (&boff)[2], int kc) {
+__device__ __forceinline__ void tap_off_pm(int tap, int r, int h, int (&boff)[2]) {  // position-major units
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1, xx = (r & 7) + dx;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const char* bp = in + (boff[nt] ^ (kc << 5));  // chunk 2 kc + h: the XOR stays inside the cell
-#pragma unroll
-        for (int p = 0; p < G::PW; ++p) b[p][nt] = *reinterpret_cast<const bf16x8*>(bp + p * G::TILE);
+        int yy = 4 * nt + (r >> 3) + dy;
+        bool inb = (unsigned)yy < 8u;
+        // 128-B cells pair up in a bank row: take the zero cell (index 0 or 9) with the parity of the virtual cell
+        int zero = G::C == 64 && ((yy + xx + 1) & 1) ? G::ROWC * G::CELL : 0;
+        boff[nt] = (inb ? G::cell_at(yy, xx) : zero) + ((G::sw(yy, xx) ^ h) << 4);
     }
 }
-template <class G>
-__device__ __forceinline__ void mfma8(f32x16 (&acc)[G::MW][G::PW][2], const bf16x8 (&a)[G::MW],
-                                      const bf16x8 (&b)[G::PW][2]) {
+// activation fragments of k-step kc for the units tap TAP needs (position-major units: all of them, whatever TAP)
+template <class G, int TAP>
+__device__ __forceinline__ void load_b(bf16x8 (&b)[G::NU], const char* in, const int (&boff)[2], int kc) {
+    constexpr int dy = TAP / 3 - 1;
+#pragma unroll
+    for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u) {
+        if constexpr (G::ROWT)
+            b[u] = *reinterpret_cast<const bf16x8*>(in + (boff[0] ^ (kc << 5)) + G::unit_imm(u) + dy * G::ROWC * G::CELL);
+        else  // chunk 2 kc + h: the XOR stays inside the cell
+            b[u] = *reinterpret_cast<const bf16x8*>(in + (boff[u & 1] ^ (kc << 5)) + (u >> 1) * G::TILE);
+    }
+}
+template <class G, int TAP>
+__device__ __forceinline__ void mfma_units(f32x16 (&acc)[G::MW][G::NU], const bf16x8 (&a)[G::MW], const bf16x8 (&b)[G::NU]) {
+    constexpr int dy = TAP / 3 - 1;
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt)
 #pragma unroll
-        for (int p = 0; p < G::PW; ++p)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-            {
-                acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[p][nt], acc[mt][p][nt], 0, 0, 0);
+        for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u)
+        {
+            acc[mt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[u], acc[mt][u], 0, 0, 0);
 #ifdef BZ_EXP_NOPS  // diagnostic duty sweep (tools/exp_duty_sweep.sh): BZ_EXP_NOPS x 8 idle issue cycles behind every MFMA
 #pragma unroll
-                for (int z = 0; z < BZ_EXP_NOPS; ++z) asm volatile("s_nop 7");
+            for (int z = 0; z < BZ_EXP_NOPS; ++z) asm volatile("s_nop 7");
 #endif
 #ifdef BZ_EXP_NOP1  // finer steps: BZ_EXP_NOP1 x 1 idle issue cycle
 #pragma unroll
-                for (int z = 0; z < BZ_EXP_NOP1; ++z) asm volatile("s_nop 0");
+            for (int z = 0; z < BZ_EXP_NOP1; ++z) asm volatile("s_nop 0");
 #endif
-            }
+        }
 }
 
-// One weight chunk = KS k-steps of 8 MFMAs (a whole conv tap at C <= 128, half a tap at C = 256).  The chunk's weight
-// fragments are in register set S of DEPTH; the set freed by the previous chunk is filled for the chunk DEPTH - 1
-// ahead (coalesced 1 KB loads; the fragment stream is linear over chunks, taps and layers).  Activation fragments are double-
-// buffered (b0/b1): the ds_read_b128 of k-step k+1 are issued between the MFMAs of k-step k.  `in` points at the wave's
-// first position; (boff, kc0) address this chunk, (tap_n, kc0_n) the next one.
+// One weight chunk CC = KS k-steps of up to 8 MFMAs (a whole conv tap at C <= 128, half a tap at C = 256); the tap is a
+// compile-time constant, so the units it skips cost nothing.  The chunk's weight fragments are in register set S of
+// DEPTH; the set freed by the previous chunk is filled for the chunk DEPTH - 1 ahead (coalesced 1 KB loads; the fragment
+// stream is linear over chunks, taps and layers).  Activation fragments are double-buffered: the ds_read_b128
+// of k-step k+1 are issued between the MFMAs of k-step k.  `in` points at the wave's first position; boff addresses
+// this chunk's tap and is replaced by the next chunk's on exit.
 template <class G> struct WSets { bf16x8 s[G::DEPTH][G::KS][G::MW]; };  // the weight-fragment register sets
 
-template <int S, class G>
-__device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::PW][2], WSets<G>& WS, const uint4*& ap, const char* in,
-                                           int (&boff)[2], int kc0, int tap_n, int kc0_n, int r, int h,
-                                           bf16x8 (&b0)[G::PW][2], bf16x8 (&b1)[G::PW][2]) {
+template <int S, int CC, class G>
+__device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::NU], WSets<G>& WS, const uint4*& ap, const char* in,
+                                           int (&boff)[2], int r, int h, bf16x8 (&B)[G::NBUF][G::NU]) {
+    constexpr int TAP = CC / G::CPT, kc0 = (CC % G::CPT) * G::KS;
+    constexpr bool last = CC + 1 >= G::NCH;  // the layer's last chunk has no successor to read ahead for
+    constexpr int TAP_N = last ? TAP : (CC + 1) / G::CPT, kc0_n = last ? 0 : ((CC + 1) % G::CPT) * G::KS;
     bf16x8 (&use)[G::KS][G::MW] = WS.s[S];
     bf16x8 (&nxt)[G::KS][G::MW] = WS.s[(S + G::DEPTH - 1) % G::DEPTH];  // the set the previous chunk has just freed
 #pragma unroll
@@ -311,28 +366,77 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::PW][2], WSets
 #pragma unroll
         for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
     ap += G::KS * G::MT * 64;
-    int boff_n[2];
-    tap_off<G>(tap_n, r, h, boff_n);
+    static_assert(G::ROWT, "compile-time taps are for row-tile units");
+    int boff_n[2] = {boff[0], boff[1]};
+    if constexpr (TAP_N % 3 != TAP % 3) tap_off<G, TAP_N>(r, h, boff_n);
+    // k-step k of this chunk sits in buffer (base + k) % NBUF; the fragments of k-step k + D are fetched while k runs
+    constexpr int NB = G::NBUF, D = NB - 1, base = (CC * G::KS) % NB;
 #pragma unroll
-    for (int k2 = 0; k2 < G::KS / 2; ++k2) {
-        load_b<G>(b1, in, boff, kc0 + 2 * k2 + 1);
-        mfma8<G>(acc, use[2 * k2], b0);
-        if (k2 < G::KS / 2 - 1) load_b<G>(b0, in, boff, kc0 + 2 * k2 + 2);
-        else load_b<G>(b0, in, boff_n, kc0_n);  // first k-step of the next chunk
-        mfma8<G>(acc, use[2 * k2 + 1], b1);
+    for (int k = 0; k < G::KS; ++k) {
+        if (k + D < G::KS) load_b<G, TAP>(B[(base + k + D) % NB], in, boff, kc0 + k + D);
+        else if constexpr (!last) load_b<G, TAP_N>(B[(base + k + D) % NB], in, boff_n, kc0_n + k + D - G::KS);  // next chunk
+        mfma_units<G, TAP>(acc, use[k], B[(base + k) % NB]);
     }
+    constexpr int NA = G::unit_hi(TAP / 3 - 1) - G::unit_lo(TAP / 3 - 1);
 #pragma unroll
     for (int i = 0; i < G::KS; ++i) {
         if (G::MW == 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NA; ++j) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NA; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+                if (j & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 VMEM reads per k-step
+            }
+        }
+    }
+    boff[0] = boff_n[0]; boff[1] = boff_n[1];
+    // the layer is straight-line code now: keep one chunk per scheduling region (the group-barrier solver is
+    // super-linear in the region size)
+    __builtin_amdgcn_sched_barrier(0);
+}
+// The same for position-major units (nothing to skip): the tap is a run-time value, so a layer is a loop over
+// chunks unrolled by DEPTH only (straight-line layers cost these shapes their register budget).
+template <int S, class G>
+__device__ __forceinline__ void chunk_step_pm(f32x16 (&acc)[G::MW][G::NU], WSets<G>& WS, const uint4*& ap, const char* in,
+                                              int (&boff)[2], int kc0, int tap_n, int kc0_n, int r, int h,
+                                              bf16x8 (&b0)[G::NU], bf16x8 (&b1)[G::NU]) {
+    constexpr int ANY = 4;  // every tap uses all units
+    bf16x8 (&use)[G::KS][G::MW] = WS.s[S];
+    bf16x8 (&nxt)[G::KS][G::MW] = WS.s[(S + G::DEPTH - 1) % G::DEPTH];
+#pragma unroll
+    for (int kc = 0; kc < G::KS; ++kc)
+#pragma unroll
+        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+    ap += G::KS * G::MT * 64;
+    int boff_n[2];
+    tap_off_pm<G>(tap_n, r, h, boff_n);
+#pragma unroll
+    for (int k2 = 0; k2 < G::KS / 2; ++k2) {
+        load_b<G, ANY>(b1, in, boff, kc0 + 2 * k2 + 1);
+        mfma_units<G, ANY>(acc, use[2 * k2], b0);
+        if (k2 < G::KS / 2 - 1) load_b<G, ANY>(b0, in, boff, kc0 + 2 * k2 + 2);
+        else load_b<G, ANY>(b0, in, boff_n, kc0_n);  // first k-step of the next chunk
+        mfma_units<G, ANY>(acc, use[2 * k2 + 1], b1);
+    }
+#pragma unroll
+    for (int i = 0; i < G::KS; ++i) {
+        if (G::MW == 1) {
+#pragma unroll
+            for (int j = 0; j < G::NU; ++j) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::NU; ++j) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
                 if (j & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 2 VMEM reads per k-step
@@ -341,13 +445,22 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::PW][2], WSets
     }
     boff[0] = boff_n[0]; boff[1] = boff_n[1];
 }
+template <int S0, int CC, class G>
+__device__ __forceinline__ void run_chunks(f32x16 (&acc)[G::MW][G::NU], WSets<G>& WS, const uint4*& ap, const char* in,
+                                           int (&boff)[2], int r, int h, bf16x8 (&B)[G::NBUF][G::NU]) {
+    if constexpr (CC < G::NCH) {  // the register-set index and the tap must be compile-time constants
+        chunk_step<(S0 + CC) % G::DEPTH, CC, G>(acc, WS, ap, in, boff, r, h, B);
+        run_chunks<S0, CC + 1, G>(acc, WS, ap, in, boff, r, h, B);
+    }
+}
 
-// +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = cell]: lane (r, h) register 4q+i of M-tile wt
-// holds co = 32wt + 8q + 4h + i of cell 32nt + r, i.e. 4 consecutive channels = one 8-byte store.
+// +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = lane column r of unit u]: lane (r, h) register 4q+i of
+// M-tile wt holds co = 32wt + 8q + 4h + i of that cell, i.e. 4 consecutive channels = one 8-byte store.
 // `out` points at the wave's first position.
 template <class G>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::PW][2], char* out, bool second,
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out, bool second,
                                          const float* __restrict__ bl, int wt0, int r, int h) {
+    const int home = G::lane_home(r) + 8 * h, swz = G::sw(r >> 3, r & 7);
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt) {
         const int wt = wt0 + mt;
@@ -355,24 +468,21 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::PW][2], char* o
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * wt + 4 * h + 8 * q);
 #pragma unroll
-        for (int p = 0; p < G::PW; ++p)
+        for (int u = 0; u < G::NU; ++u) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                int cell = 32 * nt + r;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    int off = p * G::TILE + G::cell_off(cell, 4 * wt + q) + 8 * h;
-                    f32x4 v = {acc[mt][p][nt][4 * q], acc[mt][p][nt][4 * q + 1], acc[mt][p][nt][4 * q + 2], acc[mt][p][nt][4 * q + 3]};
-                    v = v + bq[q];
-                    if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
-                        bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
-                        v = v + __builtin_convertvector(sk, f32x4);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-                    *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
+            for (int q = 0; q < 4; ++q) {
+                int off = G::unit_imm(u) + home + (((4 * wt + q) ^ swz) << 4);
+                f32x4 v = {acc[mt][u][4 * q], acc[mt][u][4 * q + 1], acc[mt][u][4 * q + 2], acc[mt][u][4 * q + 3]};
+                v = v + bq[q];
+                if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
+                    bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+                    v = v + __builtin_convertvector(sk, f32x4);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
+                *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
             }
+        }
     }
 }
 
@@ -384,31 +494,39 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
                                            unsigned long long (&tacc)[4]) {
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
-    f32x16 acc[G::MW][G::PW][2];
+    f32x16 acc[G::MW][G::NU];
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt)
 #pragma unroll
-        for (int p = 0; p < G::PW; ++p) { acc[mt][p][0] = (f32x16)(0.0f); acc[mt][p][1] = (f32x16)(0.0f); }
+        for (int u = 0; u < G::NU; ++u) acc[mt][u] = (f32x16)(0.0f);
     const int wpos = G::pos0(w) * G::TILE;
     in += wpos; out += wpos;
     int boff[2];
-    tap_off<G>(0, r, h, boff);
-    bf16x8 b0[G::PW][2], b1[G::PW][2];
-    load_b<G>(b0, in, boff, 0);
-    // chunk c covers tap c / CPT, k-steps (c % CPT) * KS ..; the chunk after the last one is a harmless re-read
-    auto tap_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return c / G::CPT; };
-    auto kc0_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return (c % G::CPT) * G::KS; };
-    constexpr int D = G::DEPTH, R = G::NCH % D, C0 = G::NCH - R;
-#define BZ_CHUNK(J, CC) chunk_step<(S0 + (J)) % D, G>(acc, WS, ap, in, boff, kc0_of(CC), tap_of((CC) + 1), kc0_of((CC) + 1), r, h, b0, b1)
+    if constexpr (G::ROWT) {
+        bf16x8 B[G::NBUF][G::NU];
+        tap_off<G, 0>(r, h, boff);
+#pragma unroll
+        for (int k = 0; k + 1 < G::NBUF; ++k) load_b<G, 0>(B[k], in, boff, k);
+        run_chunks<S0, 0, G>(acc, WS, ap, in, boff, r, h, B);
+    } else {
+        bf16x8 b0[G::NU], b1[G::NU];
+        tap_off_pm<G>(0, r, h, boff);
+        load_b<G, 4>(b0, in, boff, 0);
+        // chunk c covers tap c / CPT, k-steps (c % CPT) * KS ..; the chunk after the last one is a harmless re-read
+        auto tap_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return c / G::CPT; };
+        auto kc0_of = [](int c) { c = c < G::NCH ? c : G::NCH - 1; return (c % G::CPT) * G::KS; };
+        constexpr int D = G::DEPTH, R = G::NCH % D, C0 = G::NCH - R;
+#define BZ_CHUNK(J, CC) chunk_step_pm<(S0 + (J)) % D, G>(acc, WS, ap, in, boff, kc0_of(CC), tap_of((CC) + 1), kc0_of((CC) + 1), r, h, b0, b1)
 #pragma unroll 1
-    for (int c = 0; c + D <= G::NCH; c += D) {  // the register-set index must be a compile-time constant: unroll by DEPTH
-        BZ_CHUNK(0, c);
-        BZ_CHUNK(1, c + 1);
-        if constexpr (D >= 3) BZ_CHUNK(2, c + 2);
-    }
-    if constexpr (R >= 1) BZ_CHUNK(C0, C0);
-    if constexpr (R >= 2) BZ_CHUNK(C0 + 1, C0 + 1);
+        for (int c = 0; c + D <= G::NCH; c += D) {  // the register-set index must be a compile-time constant: unroll by DEPTH
+            BZ_CHUNK(0, c);
+            BZ_CHUNK(1, c + 1);
+            if constexpr (D >= 3) BZ_CHUNK(2, c + 2);
+        }
+        if constexpr (R >= 1) BZ_CHUNK(C0, C0);
+        if constexpr (R >= 2) BZ_CHUNK(C0 + 1, C0 + 1);
 #undef BZ_CHUNK
+    }
     BZ_STAMP(t1);
     epilogue<G>(acc, out, second, bl, G::wt0(w), r, h);
     BZ_STAMP(t2);
@@ -485,10 +603,11 @@ k_tower_bf16(TowerArgs T) {
     char* bufM = smem + G::BUF;
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- zero regions (conv halo) of both buffers
-    for (int i = tid; i < 2 * P * (G::ZERO / 16); i += 256) {
-        int k = i % (G::ZERO / 16), p = (i / (G::ZERO / 16)) % P, b = i / (P * (G::ZERO / 16));
-        *reinterpret_cast<uint4*>(smem + b * G::BUF + p * G::TILE + 64 * G::CELL + k * 16) = make_uint4(0, 0, 0, 0);
+    // ---- zero cells (conv halo: cell indices 0, 9, .., 72 of every position) of both buffers
+    constexpr int ZC = G::CELL / 16;  // 16-byte chunks per cell
+    for (int i = tid; i < 2 * P * 9 * ZC; i += 256) {
+        int k = i % ZC, j = (i / ZC) % 9, pb = i / (9 * ZC);  // pb = buffer * P + position: BUF = P * TILE
+        *reinterpret_cast<uint4*>(smem + pb * G::TILE + j * G::ROWC * G::CELL + k * 16) = make_uint4(0, 0, 0, 0);
     }
     // weight-fragment stream of this wave: k-step ks, M-tile mt -> wf[(ks * MT + mt) * 64 + lane], linear over layers
     const int wt0 = G::wt0(w), wp0 = G::pos0(w);
@@ -505,28 +624,32 @@ k_tower_bf16(TowerArgs T) {
 
     // ---- stem: conv3x3 2 -> C as a [C x 32] x [32 x 64] GEMM per position
     {
-        f32x16 acc[MW][PW][2];
+        f32x16 acc[MW][G::NU];
         bf16x8 sa[2][MW];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
             for (int mt = 0; mt < MW; ++mt) sa[kc][mt] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * G::MT + wt0 + mt) * 64 + lane]);
+        constexpr int NB = G::ROWT ? 1 : PW;  // row-tile units: every lane feeds ONE position (r >> 3) in all units
+        u64 own[NB], opp[NB];
 #pragma unroll
-        for (int p = 0; p < PW; ++p) {
-            int pos = pos0 + wp0 + p < T.n ? pos0 + wp0 + p : T.n - 1;
-            u64 own = T.own[pos], opp = T.opp[pos];
+        for (int i = 0; i < NB; ++i) {
+            int pos = pos0 + wp0 + (G::ROWT ? r >> 3 : i);
+            pos = pos < T.n ? pos : T.n - 1;
+            own[i] = T.own[pos]; opp[i] = T.opp[pos];
+        }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                bf16x8 sf[2];
+        for (int u = 0; u < G::NU; ++u) {
+            const int i = G::ROWT ? 0 : u >> 1;
+            bf16x8 sf[2];
 #pragma unroll
-                for (int kc = 0; kc < 2; ++kc) sf[kc] = stem_frag(own, opp, 32 * nt + r, 16 * kc + 8 * h);
+            for (int kc = 0; kc < 2; ++kc) sf[kc] = stem_frag(own[i], opp[i], G::unit_cell(u, r), 16 * kc + 8 * h);
 #pragma unroll
-                for (int mt = 0; mt < MW; ++mt) {
-                    acc[mt][p][nt] = (f32x16)(0.0f);
+            for (int mt = 0; mt < MW; ++mt) {
+                acc[mt][u] = (f32x16)(0.0f);
 #pragma unroll
-                    for (int kc = 0; kc < 2; ++kc)
-                        acc[mt][p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc][mt], sf[kc], acc[mt][p][nt], 0, 0, 0);
-                }
+                for (int kc = 0; kc < 2; ++kc)
+                    acc[mt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc][mt], sf[kc], acc[mt][u], 0, 0, 0);
             }
         }
         epilogue<G>(acc, bufX + wp0 * G::TILE, false, T.stem_b, wt0, r, h);
@@ -554,7 +677,7 @@ k_tower_bf16(TowerArgs T) {
 #pragma unroll
             for (int kc = 0; kc < G::KC; ++kc) {
                 bf16x8 a = __builtin_bit_cast(bf16x8, T.head_wf[kc * 64 + lane]);
-                bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * G::TILE + G::cell_off(cell, 2 * kc + h));
+                bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * G::TILE + G::cell_off(p, cell, 2 * kc + h));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
             }
             if (h == 0) {  // rows 0..2 of D live in registers 0..2 of lanes 0..31
@@ -609,60 +732,68 @@ k_tower_bf16(TowerArgs T) {
 // (betazero_amd/quant.py, oracle mode 2): weights e4m3(w * s_co) with a per-output-channel
 // power-of-two scale, activations stored as e4m3(x * 16); the epilogue multiplies the fp32
 // accumulator by 1/(s_co * 16), adds bias (+ skip / 16), ReLUs, clamps to 448/16 and converts.
-// LDS image: cell = 128 B (8 chunks of 16 B), chunk c of cell (y, x) at slot c ^ sw,
-// sw = (x>>1) | (y&1)<<2; a 256-B bank row holds two cells (x parity), so the 16 lanes of a
-// ds_read_b128 group hit 16 distinct slots; the halo lanes read a 256-B zero region.
+// Units and LDS image as in the bf16 kernel's row-tile shape: the wave's eight 32-cell units are the eight BOARD ROWS
+// of its four positions (lane r -> position r >> 3, column r & 7), so a tap with row shift dy = -1 skips unit 0 and
+// dy = +1 skips unit 7 (their inputs are zero padding): 8.3 % fewer MFMAs, bit-identical sums.  A position is 73
+// cells of 128 B (8 chunks of 16 B): 8 rows at a pitch of 9 cells (8 squares + a zero cell that is the x = 8 halo of
+// its row and the x = -1 halo of the next) + one leading zero cell.  Chunk c of a cell sits at slot c ^ sw,
+// sw = (x >> 1) | (position & 1) << 2; a 256-B bank row holds two cells (cell-index parity = x parity inside a
+// ds_read_b128 lane group), so the group's 16 lanes (8 columns x 2 positions) hit 16 distinct slots for every tap.
 // ====================================================================================
 namespace f8 {
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kZero = 64 * 128;
-constexpr int kTile = kZero + 256;  // 8,448
-constexpr int kBuf = 4 * kTile;     // 33,792
-constexpr int kLds = 2 * kBuf;      // 67,584
+constexpr int kCell = 128, kRowC = 9;
+constexpr int kTile = (8 * kRowC + 1) * kCell;  // 9,344
+constexpr int kBuf = 4 * kTile;                 // 37,376
+constexpr int kLds = 2 * kBuf;                  // 74,752: two workgroups per CU
 constexpr float kActScale = 16.0f;
 constexpr int kUnit = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
 
-__device__ __forceinline__ int cell_base(int yy, int xx, int h) {  // chunk 2h of the cell; caller XORs (ks << 6) / 16
-    const bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u;
-    const int xv = xx & 7;
-    const int sw = ((xv >> 1) & 3) | ((yy & 1) << 2);
-    const int base = inb ? (yy * 8 + xx) * 128 : kZero + (xv & 1) * 128;
-    return base + (((2 * h) ^ sw) << 4);
+__device__ __forceinline__ constexpr int cell_at(int y, int x) { return (y * kRowC + x + 1) * kCell; }  // x = -1 .. 8
+__device__ __forceinline__ int sw3(int p, int x) { return ((x & 7) >> 1) | ((p & 1) << 2); }
+// per-lane offset (from the workgroup's first position) of chunk 2h of the cell in row 0, column x + DX of the lane's
+// position; the caller XORs (ks << 6) in and adds the unit's row as a compile-time offset
+template <int DX>
+__device__ __forceinline__ int tap_off(int r, int h) {
+    const int xx = (r & 7) + DX;
+    return (r >> 3) * kTile + cell_at(0, xx) + (((2 * h) ^ sw3(r >> 3, xx)) << 4);
 }
-__device__ __forceinline__ void tap_off(int tap, int r, int h, int (&boff)[2]) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        int cell = 32 * nt + r;
-        boff[nt] = cell_base((cell >> 3) + dy, (cell & 7) + dx, h);
-    }
-}
-__device__ __forceinline__ v8i ld32(const char* p0, int off) {
-    v4i lo = *reinterpret_cast<const v4i*>(p0 + off);
-    v4i hi = *reinterpret_cast<const v4i*>(p0 + (off ^ 16));
+__device__ __forceinline__ v8i ld32(const char* p0, int off, int imm) {
+    v4i lo = *reinterpret_cast<const v4i*>(p0 + off + imm);
+    v4i hi = *reinterpret_cast<const v4i*>(p0 + (off ^ 16) + imm);
     v8i v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return v;
 }
-// activation fragments of one half-step: positions 2*pp, 2*pp+1 x 2 cell tiles
-__device__ __forceinline__ void load_b(v8i (&b)[2][2], const char* in, const int (&boff)[2], int ks, int pp) {
+constexpr int unit_lo(int dy) { return dy < 0 ? 1 : 0; }
+constexpr int unit_hi(int dy) { return dy > 0 ? 7 : 8; }
+// activation fragments of one half-step (units 4 pp .. 4 pp + 3 = board rows) of k-step ks for tap TAP
+template <int TAP>
+__device__ __forceinline__ void load_b(v8i (&b)[4], const char* in, int boff, int ks, int pp) {
+    constexpr int dy = TAP / 3 - 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b[q][nt] = ld32(in + (2 * pp + q) * kTile, boff[nt] ^ (ks << 6));
+    for (int j = 0; j < 4; ++j) {
+        const int u = 4 * pp + j;
+        if (u >= unit_lo(dy) && u < unit_hi(dy)) b[j] = ld32(in, boff ^ (ks << 6), (u + dy) * kRowC * kCell);
+    }
 }
-__device__ __forceinline__ void mfma4(f32x16 (&acc)[4][2], const v8i& a, const v8i (&b)[2][2], int pp) {
+template <int TAP>
+__device__ __forceinline__ void mfma4(f32x16 (&acc)[8], const v8i& a, const v8i (&b)[4], int pp) {
+    constexpr int dy = TAP / 3 - 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            acc[2 * pp + q][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[q][nt], acc[2 * pp + q][nt], 0, 0, 0,
-                                                                               kUnit, 0, kUnit);
+    for (int j = 0; j < 4; ++j) {
+        const int u = 4 * pp + j;
+        if (u >= unit_lo(dy) && u < unit_hi(dy))
+            acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[j], acc[u], 0, 0, 0, kUnit, 0, kUnit);
+    }
 }
 
-template <int S>
-__device__ __forceinline__ void tap_step(f32x16 (&acc)[4][2], v8i (&A0)[2], v8i (&A1)[2], const uint4*& ap, const char* in,
-                                         int (&boff)[2], int next_tap, int r, int h, v8i (&b0)[2][2], v8i (&b1)[2][2]) {
+// one conv tap (compile-time: the skipped units cost nothing) = 2 k-steps x 2 half-steps of up to 4 MFMAs
+template <int S, int TAP>
+__device__ __forceinline__ void tap_step(f32x16 (&acc)[8], v8i (&A0)[2], v8i (&A1)[2], const uint4*& ap, const char* in,
+                                         int& boff, int r, int h, v8i (&b0)[4], v8i (&b1)[4]) {
+    constexpr bool last = TAP == 8;
+    constexpr int TAP_N = last ? TAP : TAP + 1;
     v8i (&use)[2] = S ? A1 : A0;
     v8i (&nxt)[2] = S ? A0 : A1;
 #pragma unroll
@@ -672,16 +803,16 @@ __device__ __forceinline__ void tap_step(f32x16 (&acc)[4][2], v8i (&A0)[2], v8i 
         nxt[ks] = v;
     }
     ap += 2 * 4 * 2 * 64;
-    int boff_n[2];
-    tap_off(next_tap, r, h, boff_n);
-    load_b(b1, in, boff, 0, 1);
-    mfma4(acc, use[0], b0, 0);
-    load_b(b0, in, boff, 1, 0);
-    mfma4(acc, use[0], b1, 1);
-    load_b(b1, in, boff, 1, 1);
-    mfma4(acc, use[1], b0, 0);
-    load_b(b0, in, boff_n, 0, 0);  // first half-step of the next tap
-    mfma4(acc, use[1], b1, 1);
+    int boff_n = boff;
+    if constexpr (TAP_N % 3 != TAP % 3) boff_n = tap_off<TAP_N % 3 - 1>(r, h);
+    load_b<TAP>(b1, in, boff, 0, 1);
+    mfma4<TAP>(acc, use[0], b0, 0);
+    load_b<TAP>(b0, in, boff, 1, 0);
+    mfma4<TAP>(acc, use[0], b1, 1);
+    load_b<TAP>(b1, in, boff, 1, 1);
+    mfma4<TAP>(acc, use[1], b0, 0);
+    if constexpr (!last) load_b<TAP_N>(b0, in, boff_n, 0, 0);  // first half-step of the next tap
+    mfma4<TAP>(acc, use[1], b1, 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -691,13 +822,22 @@ __device__ __forceinline__ void tap_step(f32x16 (&acc)[4][2], v8i (&A0)[2], v8i 
         }
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
     }
-    boff[0] = boff_n[0]; boff[1] = boff_n[1];
+    boff = boff_n;
+    __builtin_amdgcn_sched_barrier(0);  // one tap per scheduling region (straight-line layer)
+}
+template <int S0, int TAP>
+__device__ __forceinline__ void run_taps(f32x16 (&acc)[8], v8i (&A0)[2], v8i (&A1)[2], const uint4*& ap, const char* in,
+                                         int& boff, int r, int h, v8i (&b0)[4], v8i (&b1)[4]) {
+    if constexpr (TAP < 9) {
+        tap_step<(S0 + TAP) % 2, TAP>(acc, A0, A1, ap, in, boff, r, h, b0, b1);
+        run_taps<S0, TAP + 1>(acc, A0, A1, ap, in, boff, r, h, b0, b1);
+    }
 }
 
 // e4m3(16 * relu(acc * dq + bias (+ skip))) -> LDS, computed in the x16 domain: fma(acc, 16 dq, 16 bias)
 // (+ the stored skip code, which already is 16 x), one v_med3 for ReLU + saturation, cvt_pk.
-// lane (r, h) register 4q+i = channel 32w + 8q + 4h + i
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], char* out, bool second, const float* __restrict__ dq,
+// lane (r, h) register 4q+i of unit u = channel 32w + 8q + 4h + i of board cell (row u, column r & 7) of position r >> 3
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[8], char* out, bool second, const float* __restrict__ dq,
                                          const float* __restrict__ bl, int w, int r, int h) {
     f32x4 dqv[4], bq[4];
 #pragma unroll
@@ -705,31 +845,27 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], char* out, bool se
         dqv[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q) * kActScale;
         bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q) * kActScale;
     }
+    const int home = (r >> 3) * kTile + cell_at(0, r & 7) + 4 * h, sw = sw3(r >> 3, r & 7);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int cell = 32 * nt + r, y = cell >> 3, x = cell & 7;
-        const int sw = ((x >> 1) & 3) | ((y & 1) << 2);
+    for (int q = 0; q < 4; ++q) {
+        const int chunk = 2 * w + (q >> 1);
+        const int base = home + ((chunk ^ sw) << 4) + 8 * (q & 1);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int chunk = 2 * w + (q >> 1);
-            const int base = cell * 128 + ((chunk ^ sw) << 4) + 8 * (q & 1) + 4 * h;
+        for (int u = 0; u < 8; ++u) {
+            const int off = base + u * kRowC * kCell;
+            float v[4];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int off = p * kTile + base;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[p][nt][4 * q + i], dqv[q][i], bq[q][i]);
-                if (second) {
-                    int sk = *reinterpret_cast<const int*>(out + off);
-                    v[0] += __builtin_amdgcn_cvt_f32_fp8(sk, 0); v[1] += __builtin_amdgcn_cvt_f32_fp8(sk, 1);
-                    v[2] += __builtin_amdgcn_cvt_f32_fp8(sk, 2); v[3] += __builtin_amdgcn_cvt_f32_fp8(sk, 3);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.0f, 448.0f);
-                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-                *reinterpret_cast<int*>(out + off) = pk;
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[u][4 * q + i], dqv[q][i], bq[q][i]);
+            if (second) {
+                int sk = *reinterpret_cast<const int*>(out + off);
+                v[0] += __builtin_amdgcn_cvt_f32_fp8(sk, 0); v[1] += __builtin_amdgcn_cvt_f32_fp8(sk, 1);
+                v[2] += __builtin_amdgcn_cvt_f32_fp8(sk, 2); v[3] += __builtin_amdgcn_cvt_f32_fp8(sk, 3);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.0f, 448.0f);
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+            *reinterpret_cast<int*>(out + off) = pk;
         }
     }
 }
@@ -740,19 +876,13 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
                                            int w, int r, int h, unsigned long long (&tacc)[4]) {
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
-    f32x16 acc[4][2];
+    f32x16 acc[8];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { acc[p][0] = (f32x16)(0.0f); acc[p][1] = (f32x16)(0.0f); }
-    int boff[2];
-    tap_off(0, r, h, boff);
-    v8i b0[2][2], b1[2][2];
-    load_b(b0, in, boff, 0, 0);
-#pragma unroll 1
-    for (int t = 0; t < 8; t += 2) {
-        tap_step<S0>(acc, A0, A1, ap, in, boff, t + 1, r, h, b0, b1);
-        tap_step<1 - S0>(acc, A0, A1, ap, in, boff, t + 2, r, h, b0, b1);
-    }
-    tap_step<S0>(acc, A0, A1, ap, in, boff, 8, r, h, b0, b1);
+    for (int u = 0; u < 8; ++u) acc[u] = (f32x16)(0.0f);
+    int boff = tap_off<-1>(r, h);
+    v8i b0[4], b1[4];
+    load_b<0>(b0, in, boff, 0, 0);
+    run_taps<S0, 0>(acc, A0, A1, ap, in, boff, r, h, b0, b1);  // 9 taps: the weight set alternates, S0 ^ (tap & 1)
     BZ_STAMP(t1);
     epilogue(acc, out, second, dq, bl, w, r, h);
     BZ_STAMP(t2);
@@ -761,7 +891,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
 }
 
-// 67.6 KB of LDS per workgroup: two workgroups per CU hide each other's epilogues (launch bound 2 waves per SIMD)
+// 74.8 KB of LDS per workgroup: two workgroups per CU hide each other's epilogues (launch bound 2 waves per SIMD)
 __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -778,9 +908,9 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
     char* bufM = smem + kBuf;
     const int r = lane & 31, h = lane >> 5;
 
-    if (tid < 128) {  // zero regions: 2 buffers x 4 positions x 256 B
-        int k = tid & 15, p = (tid >> 4) & 3, b = tid >> 6;
-        *reinterpret_cast<uint4*>(smem + b * kBuf + p * kTile + kZero + k * 16) = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * 4 * 9 * 8; i += 256) {  // zero cells 0, 9, .., 72 of 2 buffers x 4 positions (8 x 16 B each)
+        int k = i & 7, j = (i >> 3) % 9, pb = i / 72;
+        *reinterpret_cast<uint4*>(smem + pb * kTile + j * kRowC * kCell + k * 16) = make_uint4(0, 0, 0, 0);
     }
     // weight stream: tap t, k-step ks, co-tile w, 16-byte halves: wf8[(((t*2 + ks)*4 + w)*2 + half)*64 + lane]
     const uint4* ap = T.wf8 + (size_t)(w * 2) * 64 + lane;
@@ -795,22 +925,19 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
 
     // ---- stem (bf16 MFMA, exact 0/1 inputs) -> e4m3 activations
     {
-        f32x16 acc[4][2];
+        f32x16 acc[8];
         bf16x8 sa[2];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) sa[kc] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + w) * 64 + lane]);
+        int pos = pos0 + (r >> 3) < T.n ? pos0 + (r >> 3) : T.n - 1;  // every lane feeds ONE position in all units
+        u64 own = T.own[pos], opp = T.opp[pos];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int pos = pos0 + p < T.n ? pos0 + p : T.n - 1;
-            u64 own = T.own[pos], opp = T.opp[pos];
+        for (int u = 0; u < 8; ++u) {
+            acc[u] = (f32x16)(0.0f);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                acc[p][nt] = (f32x16)(0.0f);
-#pragma unroll
-                for (int kc = 0; kc < 2; ++kc)
-                    acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc], stem_frag(own, opp, 32 * nt + r, 16 * kc + 8 * h),
-                                                                        acc[p][nt], 0, 0, 0);
-            }
+            for (int kc = 0; kc < 2; ++kc)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc], stem_frag(own, opp, 8 * u + (r & 7), 16 * kc + 8 * h),
+                                                                acc[u], 0, 0, 0);
         }
         epilogue(acc, bufX, false, T.ones, T.stem_b, w, r, h);
     }
@@ -834,12 +961,12 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
         for (int nt = 0; nt < 2; ++nt) {
             f32x16 acc = (f32x16)(0.0f);
             const int cell = 32 * nt + r;
-            const int cb = cell_base(cell >> 3, cell & 7, h);
+            const int cb = cell_at(cell >> 3, cell & 7) + (((2 * h) ^ sw3(p, cell & 7)) << 4);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 lo = T.head_wf8[(ks * 2 + 0) * 64 + lane], hi = T.head_wf8[(ks * 2 + 1) * 64 + lane];
                 v8i a = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-                v8i b = ld32(bufX + p * kTile, cb ^ (ks << 6));
+                v8i b = ld32(bufX + p * kTile, cb ^ (ks << 6), 0);
                 acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, kUnit, 0, kUnit);
             }
             if (h == 0) {
@@ -1112,10 +1239,11 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     if (urc != BZ_OK) { delete n; return urc; }
     {
         hipError_t e3 = hipSuccess;
-        if (C == 64) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<Tw<64>>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<64>::LDS);
-        if (C == 128) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<Tw<128>>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<128>::LDS);
-        if (C == 256) e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<Tw<256>>), hipFuncAttributeMaxDynamicSharedMemorySize, Tw<256>::LDS);
-        // (the latency shapes use under 64 KB of LDS: no attribute needed)
+#define BZ_TOWER_LDS(GEOM) hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<GEOM>), hipFuncAttributeMaxDynamicSharedMemorySize, GEOM::LDS)
+        if (C == 64) { e3 = BZ_TOWER_LDS(Tw<64>); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS64); }
+        if (C == 128) { e3 = BZ_TOWER_LDS(Tw<128>); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS128); }
+        if (C == 256) { e3 = BZ_TOWER_LDS(Tw<256>); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS256); }  // TwS256: 73 KB
+#undef BZ_TOWER_LDS
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
         // the f32 parity kernels stage a whole position in LDS: above 64 KB at C = 256
         if (C == 256) {

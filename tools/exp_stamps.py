@@ -21,6 +21,8 @@ d = buf.reshape(nb, 8).astype(np.float64)
 print("per WG (wave 0), cycles:  kloop %.0f  epilogue %.0f  barrier %.0f   layers-total %.0f  kernel-total %.0f" % tuple(d[:, i].mean() for i in (0, 1, 2, 3, 4)))
 clk = d[:, 4] / d[:, 5] * 100e6
 print("in-kernel clock GHz: mean %.3f min %.3f max %.3f" % (clk.mean() / 1e9, clk.min() / 1e9, clk.max() / 1e9))
-print("per layer: kloop %.0f (ideal P=4 %d)  epilogue %.0f  barrier %.0f" % (d[:, 0].mean() / 12, 72 * 8 * 32, d[:, 1].mean() / 12, d[:, 2].mean() / 12))
+# MFMA floor of the K-loop: 9 taps x 8 k-steps x 8 units x 32 cycles; the bf16 row-tile units skip one unit in 6 of the 9 taps
+floor = 72 * 8 * 32 if FP8 or os.environ.get("NO_ROWT") == "1" else (6 * 7 + 3 * 8) * 8 * 32
+print("per layer: kloop %.0f (MFMA floor %d)  epilogue %.0f  barrier %.0f" % (d[:, 0].mean() / 12, floor, d[:, 1].mean() / 12, d[:, 2].mean() / 12))
 t0 = d[:, 7]; print("WG start spread (us): ", np.percentile((t0 - t0.min()) / 100, [0, 25, 50, 75, 100]))
 print("WG duration us: mean %.1f" % (d[:, 5].mean() / 100))
