@@ -364,7 +364,7 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::NU], WSets<G>
 #pragma unroll
     for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(kc * G::MT + mt) * 64 + (unsigned)(32 * h + r)]);
     ap += G::KS * G::MT * 64;
     static_assert(G::ROWT, "compile-time taps are for row-tile units");
     int boff_n[2] = {boff[0], boff[1]};
@@ -413,7 +413,7 @@ __device__ __forceinline__ void chunk_step_pm(f32x16 (&acc)[G::MW][G::NU], WSets
 #pragma unroll
     for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(kc * G::MT + mt) * 64 + (unsigned)(32 * h + r)]);
     ap += G::KS * G::MT * 64;
     int boff_n[2];
     tap_off_pm<G>(tap_n, r, h, boff_n);
@@ -611,14 +611,16 @@ k_tower_bf16(TowerArgs T) {
     }
     // weight-fragment stream of this wave: k-step ks, M-tile mt -> wf[(ks * MT + mt) * 64 + lane], linear over layers
     const int wt0 = G::wt0(w), wp0 = G::pos0(w);
-    const uint4* ap = T.wf + (size_t)wt0 * 64 + lane;
+    // wave-uniform base (scalar registers) + lane: the loads take the SGPR-base addressing mode, so advancing the stream
+    // costs scalar adds instead of 64-bit vector adds between the MFMAs
+    const uint4* ap = T.wf + (size_t)wt0 * 64;
     WSets<G> WS;
 #pragma unroll
     for (int d = 0; d + 1 < G::DEPTH; ++d) {  // chunks 0 .. DEPTH - 2 of the first layer
 #pragma unroll
         for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-            for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, ap[(size_t)(kc * G::MT + mt) * 64]);
+            for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, ap[(kc * G::MT + mt) * 64 + (unsigned)lane]);
         ap += G::KS * G::MT * 64;
     }
 
@@ -798,7 +800,7 @@ __device__ __forceinline__ void tap_step(f32x16 (&acc)[8], v8i (&A0)[2], v8i (&A
     v8i (&nxt)[2] = S ? A0 : A1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        uint4 lo = ap[(size_t)((ks * 4) * 2 + 0) * 64], hi = ap[(size_t)((ks * 4) * 2 + 1) * 64];
+        uint4 lo = ap[((ks * 4) * 2 + 0) * 64 + (unsigned)(32 * h + r)], hi = ap[((ks * 4) * 2 + 1) * 64 + (unsigned)(32 * h + r)];
         v8i v = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
         nxt[ks] = v;
     }
@@ -913,11 +915,11 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
         *reinterpret_cast<uint4*>(smem + pb * kTile + j * kRowC * kCell + k * 16) = make_uint4(0, 0, 0, 0);
     }
     // weight stream: tap t, k-step ks, co-tile w, 16-byte halves: wf8[(((t*2 + ks)*4 + w)*2 + half)*64 + lane]
-    const uint4* ap = T.wf8 + (size_t)(w * 2) * 64 + lane;
+    const uint4* ap = T.wf8 + (size_t)(w * 2) * 64;  // wave-uniform base + lane (SGPR-base addressing)
     v8i A0[2], A1[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        uint4 lo = ap[(size_t)((ks * 4) * 2 + 0) * 64], hi = ap[(size_t)((ks * 4) * 2 + 1) * 64];
+        uint4 lo = ap[((ks * 4) * 2 + 0) * 64 + (unsigned)lane], hi = ap[((ks * 4) * 2 + 1) * 64 + (unsigned)lane];
         v8i v = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
         A0[ks] = v;
     }

@@ -12,7 +12,7 @@ template <int MODE, int NACC>
 __global__ void __launch_bounds__(256, 1) k(const uint4* __restrict__ w, float* out, unsigned long long* cyc, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 40960 / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80);
+    for (int i = threadIdx.x; i < 81920 / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80);
     __syncthreads();
     f32x16 acc[NACC];
 #pragma unroll
@@ -22,29 +22,46 @@ __global__ void __launch_bounds__(256, 1) k(const uint4* __restrict__ w, float* 
     for (int ks = 0; ks < 8; ++ks) a8[ks] = __builtin_bit_cast(bf16x8, w[ks * 64 + lane]);
     bf16x8 b[NACC];
     const char* bp = smem + lane * 16;
+    [[maybe_unused]] int boff = 0;
+    if (MODE >= 7) {  // the tower's row-tile pattern: lane (r, h) -> position r >> 3, column r & 7, 256-B cells, XOR swizzle
+        const int r = lane & 31, h = lane >> 5, p = r >> 3, x = r & 7;
+        int sw = x | ((p & 1) << 3);
+        if (MODE == 8) sw = (x << 1) | (p & 1);      // candidate: position bit in the LOW slot bit
+        if (MODE == 9) sw = x | ((p >> 1) << 3);     // candidate: pair positions (0,1) / (2,3)
+        boff = p * 18688 + (x + 1) * 256 + ((sw ^ h) << 4);
+    }
 #pragma unroll
     for (int u = 0; u < NACC; ++u) b[u] = *reinterpret_cast<const bf16x8*>(bp + u * 2304);
     const uint4* ap = w + lane;
     unsigned long long t0, t1;
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(w), 0, 1024 * 64 * 16 + 4096, 0x00020000);
     [[maybe_unused]] bf16x8 n8[8];
+    [[maybe_unused]] bf16x8 extra[NACC];
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     auto kstep = [&](bf16x8& use, bf16x8& load_into, int it, int ks, int where) {
+        if (MODE == 10) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
 #pragma unroll
         for (int u = 0; u < NACC; ++u) {
             acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(use, b[u], acc[u], 0, 0, 0);
-            if (MODE >= 1) b[u] = *reinterpret_cast<const bf16x8*>(bp + u * 2304 + ((ks & 7) << 5));
+            if (MODE >= 1) b[u] = *reinterpret_cast<const bf16x8*>(MODE >= 7 ? smem + (boff ^ ((ks & 7) << 5)) + u * 2304 : bp + u * 2304 + ((ks & 7) << 5));
+            if (MODE == 6) {  // a second, independent ds_read_b128 per MFMA: is the 1:1 ratio already the LDS's limit?
+                bf16x8 e = *reinterpret_cast<const bf16x8*>(bp + 20480 + u * 2304 + ((ks & 7) << 5));
+                extra[u] = e;
+            }
             if (u == where) {
-                if (MODE == 5) load_into = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, ((it * 8 + ks) & 1023) * 1024, 0));
-                else if (MODE >= 2) load_into = __builtin_bit_cast(bf16x8, ap[(size_t)((it * 8 + ks) & 1023) * 64]);
+                if (MODE == 10) {
+                    const uint4* sb = w + (size_t)((it * 8 + ks) & 1023) * 64;  // wave-uniform
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(load_into) : "v"(lane * 16), "s"(sb) : "memory");
+                } else if (MODE == 5) load_into = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, ((it * 8 + ks) & 1023) * 1024, 0));
+                else if (MODE >= 2 && MODE < 6) load_into = __builtin_bit_cast(bf16x8, ap[(size_t)((it * 8 + ks) & 1023) * 64]);
             }
         }
         if (MODE >= 1) {
 #pragma unroll
             for (int j = 0; j < NACC; ++j) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (MODE >= 2 && j == where) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MODE == 6 ? 2 : 1, 0);
+                if (MODE >= 2 && (MODE < 6 || MODE == 10) && j == where) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     };
@@ -67,6 +84,10 @@ __global__ void __launch_bounds__(256, 1) k(const uint4* __restrict__ w, float* 
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
     float s = 0.0f;
+    if (MODE == 6) {
+#pragma unroll
+        for (int u = 0; u < NACC; ++u) s += (float)extra[u][0];
+    }
 #pragma unroll
     for (int u = 0; u < NACC; ++u) s += acc[u][0] + acc[u][15];
     out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -104,5 +125,12 @@ int main() {
     run<4, 8>("+ weight load in the middle of the k-step", w, out, cyc, grid);
     run<5, 8>("+ weight load by buffer_load (SGPR offset)", w, out, cyc, grid);
     run<5, 7>("+ weight load by buffer_load (SGPR offset)", w, out, cyc, grid);
+    run<10, 8>("+ weight load, SGPR base + 32-bit lane offset (asm)", w, out, cyc, grid);
+    run<10, 7>("+ weight load, SGPR base + 32-bit lane offset (asm)", w, out, cyc, grid);
+    run<6, 8>("MFMA + 2 ds_read_b128 per MFMA", w, out, cyc, grid);
+    run<7, 8>("MFMA + ds_read 1:1, tower address pattern", w, out, cyc, grid);
+    run<7, 7>("MFMA + ds_read 1:1, tower address pattern", w, out, cyc, grid);
+    run<8, 8>("... swizzle candidate A", w, out, cyc, grid);
+    run<9, 8>("... swizzle candidate B", w, out, cyc, grid);
     return 0;
 }
