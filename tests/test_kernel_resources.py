@@ -20,6 +20,7 @@ def _resources(src, tmp_path):
                           stderr=subprocess.DEVNULL)
     res = {}
     txt = out.read_text()
+    _resources.asm = txt
     for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk)
         if name:
@@ -55,3 +56,23 @@ def test_net_kernels_do_not_spill(tmp_path):
         k = _find(res, *parts)
         assert k["vspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
     assert _find(res, "k_tower_fp8")["vgpr"] <= 256  # two workgroups per CU
+
+
+def _count(asm, kernel_parts, mnemonic):
+    """occurrences of an instruction in one kernel's body"""
+    for m in re.finditer(r"^(\S+):\s*; @\1$", asm, re.M):
+        if all(p in m.group(1) for p in kernel_parts):
+            body = asm[m.end():asm.index("s_endpgm", m.end())]
+            return len(re.findall(rf"^\s+{mnemonic}\b", body, re.M))
+    raise AssertionError(kernel_parts)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_towers_skip_the_padding_row_mfmas(tmp_path):
+    """Row-tile units: per conv layer a wave issues 9 taps x 8 k-steps x 8 units = 576 MFMAs minus the 6
+    taps x 8 k-steps whose unit reads only padding rows = 528 (bf16; fp8: 144 - 12 = 132).  Two layer bodies per kernel
+    + stem + heads: a regression to position-major units would show up here as 1184 / 292."""
+    _resources("bz_net.hip", tmp_path)
+    asm = _resources.asm
+    assert _count(asm, ("k_tower_bf16", "Li128ELi4E"), "v_mfma_f32_32x32x16_bf16") == 2 * 528 + 16 + 16
+    assert _count(asm, ("k_tower_fp8",), "v_mfma_scale_f32_32x32x64_f8f6f4") == 2 * 132 + 4
