@@ -36,9 +36,12 @@ class ArenaResult:
 
 
 def play_arena(game, n_games, sims, opponent_depth=4, evaluator="uniform", net=None, c_puct=1.5, seed=0, size=8,
-               device="cuda:0", max_plies=200):
+               device="cuda:0", max_plies=200, opening_plies=0):
     """MCTS (`sims` simulations, `evaluator`) vs minimax for n_games concurrent games; the MCTS side plays X
-    (moves first) in the even-numbered games and O in the odd ones.  game: "ttt" | "reversi" (size 8, 6 or 4)."""
+    (moves first) in the even-numbered games and O in the odd ones.  game: "ttt" | "reversi" (size 8, 6 or 4).
+    Both players are deterministic, so without help there are only two distinct games (one per colour):
+    `opening_plies` > 0 plays that many uniformly random legal moves (seeded) before the players take over, which
+    makes the B games B different tests."""
     _lib.require_gpu()
     L = _lib.lib()
     dev = torch.device(device)
@@ -69,12 +72,30 @@ def play_arena(game, n_games, sims, opponent_depth=4, evaluator="uniform", net=N
     status = torch.empty(B, dtype=torch.uint8, device=dev)
     win_n = torch.empty(B, dtype=torch.int8, device=dev)
     log = []
-    for _ in range(max_plies):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    valid = (1 << 9) - 1 if ttt else sum(((1 << size) - 1) << (8 * r) for r in range(size))
+    valid_t = torch.tensor(valid - (1 << 64) if valid >= 1 << 63 else valid, dtype=torch.int64, device=dev)
+    shifts = torch.arange(64, dtype=torch.int64, device=dev)
+    for ply in range(max_plies):
         if not bool(active.any()):
             break
         mcts_turn = active & (to_move == mcts_colour)
         mm_turn = active & ~mcts_turn
         action = torch.full((B,), 255, dtype=torch.uint8, device=dev)
+        if ply < opening_plies:  # a random legal move for every game, by neither player
+            if ttt:
+                legal = ~(own | opp).to(torch.int64) & valid_t
+            else:
+                legal = torch.empty(B, dtype=torch.int64, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(L.bz_reversi_legal_batch(own.data_ptr(), opp.data_ptr(), B, legal.data_ptr(), st()))
+                legal = legal & valid_t
+            bits = ((legal.unsqueeze(1) >> shifts) & 1).bool()
+            draw = torch.rand((B, 64), generator=gen, device=dev)
+            pick = torch.where(bits, draw, torch.full_like(draw, -1.0)).argmax(1).to(torch.uint8)
+            action = torch.where(active, pick, action)
+            mcts_turn = mm_turn = torch.zeros_like(active)
         if bool(mcts_turn.any()):
             roots_tm = torch.where(mcts_turn, to_move, torch.zeros_like(to_move))
             o64 = own.to(torch.int64) if ttt else own

@@ -508,6 +508,23 @@ def test_arena_batched_mcts_never_loses_to_minimax_at_tictactoe():
     assert set(res.mcts_colour.tolist()) == {1, -1}
 
 
+def test_arena_random_openings_make_the_games_different_and_reproducible():
+    """both arena players are deterministic (two distinct games without help): `opening_plies` seeded random legal
+    moves diversify them; the same seed replays the same games, every opening move is legal (the env step would
+    raise), and the players take over afterwards"""
+    from betazero_amd.arena import play_arena
+    a = play_arena("reversi", 64, 32, opponent_depth=1, evaluator="uniform", seed=3, opening_plies=4)
+    b = play_arena("reversi", 64, 32, opponent_depth=1, evaluator="uniform", seed=3, opening_plies=4)
+    seq = lambda r: [tuple(int(act[g]) for act, _ in r.moves) for g in range(64)]  # noqa: E731
+    assert seq(a) == seq(b) and np.array_equal(a.winner, b.winner)
+    assert len(set(seq(a))) >= 32, len(set(seq(a)))
+    assert len({s[:4] for s in seq(a)}) >= 16  # the openings themselves differ
+    c = play_arena("reversi", 64, 32, opponent_depth=1, evaluator="uniform", seed=3)
+    assert len(set(seq(c))) <= 2
+    t = play_arena("ttt", 32, 200, evaluator="uniform", seed=2, opening_plies=2)
+    assert t.summary()["games"] == 32 and len({tuple(int(act[g]) for act, _ in t.moves[:2]) for g in range(32)}) >= 8
+
+
 def test_arena_batched_reversi_mcts_vs_depth_limited_minimax():
     """64 concurrent 8x8 games, MCTS (300 sims, hash evaluator -- there is no trained net in this repo, so no
     strength is asserted) vs the reference's OptimalPlayer at depth 2 (kernel): every game must be a legal game of

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""The closed AlphaZero loop on one GPU, end to end through the package's public pieces:
+
+    self-play (SelfPlayEngine, bf16 MFMA net in the loop, Dirichlet root noise, temperature moves)
+      -> example block -> 8-fold D4 augmentation + dedupe on the device (augment_examples)
+      -> policy cross-entropy + value MSE steps with stock PyTorch autograd (train_step)
+      -> weights pushed back into the engine's net (refresh_device_net)
+      -> batched arena against the reference's depth-limited minimax player (play_arena)
+
+It prints one JSON line per iteration and a final summary; `--out` keeps them.  The yard-stick is the reference's
+OptimalPlayer (src/reversi/players/reversi_players.py:35-77, stone-difference minimax) at `--depth`; the same arena
+with the uniform evaluator (no net) is printed first as the untrained reference point.
+
+    python tools/az_loop.py --iters 8            # a few minutes on one MI355X
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from betazero_amd.arena import play_arena  # noqa: E402
+from betazero_amd.augment import augment_examples  # noqa: E402
+from betazero_amd.engine import SelfPlayEngine, concat_examples  # noqa: E402
+from betazero_amd.net import DeviceNet, PolicyValueNet  # noqa: E402
+from betazero_amd.train import make_optimizer, refresh_device_net, train_step  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--channels", type=int, default=64, choices=(64, 128, 256))
+    ap.add_argument("--blocks", type=int, default=4)
+    ap.add_argument("--games", type=int, default=2048, help="concurrent self-play games per iteration")
+    ap.add_argument("--sims", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--window", type=int, default=3, help="iterations of examples kept for training")
+    ap.add_argument("--epochs", type=float, default=1.0, help="passes over the (augmented) window per iteration")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--temp-moves", type=int, default=10)
+    ap.add_argument("--arena-games", type=int, default=256)
+    ap.add_argument("--arena-sims", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=3, help="search depth of the minimax opponent")
+    ap.add_argument("--final-depths", default="1,3,5", help="minimax depths the final net is also played against")
+    ap.add_argument("--opening-plies", type=int, default=4, help="random legal moves before the arena players take over")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    torch.manual_seed(args.seed)
+    rng = np.random.default_rng(args.seed)
+    module = PolicyValueNet(args.channels, args.blocks, 64)
+    opt = make_optimizer(module, lr=args.lr)
+    bmax = max(args.games, args.arena_games)
+    dnet = DeviceNet.from_module(module.round_to_bf16_(), bmax)
+    lines = []
+
+    def emit(d):
+        lines.append(d)
+        print(json.dumps(d), flush=True)
+
+    def arena(evaluator, net, depth=None):
+        t0 = time.time()
+        res = play_arena("reversi", args.arena_games, args.arena_sims, opponent_depth=depth or args.depth, evaluator=evaluator,
+                         net=net, seed=args.seed, opening_plies=args.opening_plies)
+        s = res.summary()
+        s["score"] = round((s["wins"] + 0.5 * s["draws"]) / s["games"], 4)
+        s["seconds"] = round(time.time() - t0, 1)
+        return s
+
+    emit({"what": "arena, MCTS with the uniform evaluator (no net)", "sims": args.arena_sims, "opponent_depth": args.depth,
+          **arena("uniform", None)})
+    emit({"what": "arena, untrained net", "iter": 0, **arena("net_bf16", dnet)})
+
+    window = []
+    for it in range(1, args.iters + 1):
+        t0 = time.time()
+        eng = SelfPlayEngine("reversi", args.games, args.sims, "net_bf16", dnet, temp_moves=args.temp_moves, openings=1,
+                             seed=args.seed * 1000 + it, dirichlet_alpha=0.3, dirichlet_eps=0.25)
+        plies = eng.run_iteration()
+        ex = eng.examples()
+        winners, _ = eng.winners()
+        del eng
+        t_play = time.time() - t0
+        t1 = time.time()
+        aug = augment_examples(ex, dedupe=True)
+        window = (window + [aug])[-args.window:]
+        data = concat_examples(window)
+        steps = max(1, int(args.epochs * len(data) / args.batch))
+        losses = []
+        for _ in range(steps):
+            idx = rng.integers(0, len(data), size=args.batch)
+            losses.append(train_step(module, opt, data, idx))
+        refresh_device_net(dnet, module)
+        t_train = time.time() - t1
+        head, tail = np.mean(losses[: max(1, steps // 10)], axis=0), np.mean(losses[-max(1, steps // 10):], axis=0)
+        emit({"what": "iteration", "iter": it, "games": args.games, "plies": plies, "examples": int(len(ex)),
+              "augmented_rows": int(len(aug)), "train_rows": int(len(data)), "steps": steps,
+              "loss_first_tenth": [round(float(x), 4) for x in head], "loss_last_tenth": [round(float(x), 4) for x in tail],
+              "self_play_x_wins": int((winners > 0).sum()), "self_play_o_wins": int((winners < 0).sum()),
+              "self_play_s": round(t_play, 1), "games_per_s": round(args.games / t_play, 1), "train_s": round(t_train, 1),
+              "arena": arena("net_bf16", dnet)})
+    for d in (int(x) for x in args.final_depths.split(",") if x):
+        emit({"what": "final arena", "opponent_depth": d, "sims": args.arena_sims, "trained": arena("net_bf16", dnet, d),
+              "uniform_evaluator": arena("uniform", None, d)})
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump({"args": vars(args), "lines": lines}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
