@@ -274,6 +274,9 @@ template <int C_, int P_ = 512 / C_> struct Tw {
 };
 
 // Diagnostic build only (tools/exp_stamps.sh -> a separate libbz_hip.stamps.so, never the product .so)
+#if defined(BZ_EXP_STAMPS_TAPS) && !defined(BZ_EXP_STAMPS)
+#error "BZ_EXP_STAMPS_TAPS needs BZ_EXP_STAMPS"
+#endif
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
@@ -449,7 +452,15 @@ template <int S0, int CC, class G>
 __device__ __forceinline__ void run_chunks(f32x16 (&acc)[G::MW][G::NU], WSets<G>& WS, const uint4*& ap, const char* in,
                                            int (&boff)[2], int r, int h, bf16x8 (&B)[G::NBUF][G::NU]) {
     if constexpr (CC < G::NCH) {  // the register-set index and the tap must be compile-time constants
+#ifdef BZ_EXP_STAMPS_TAPS  // per-tap cycles of workgroup 0, wave 0 (each stamp drains the LDS queue: it perturbs the layer totals)
+        unsigned long long c0, c1;
+        BZ_STAMP(c0);
+#endif
         chunk_step<(S0 + CC) % G::DEPTH, CC, G>(acc, WS, ap, in, boff, r, h, B);
+#ifdef BZ_EXP_STAMPS_TAPS
+        BZ_STAMP(c1);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { g_dbg[8 * 2048 + CC] += c1 - c0; g_dbg[8 * 2048 + 32 + CC] += 1; }
+#endif
         run_chunks<S0, CC + 1, G>(acc, WS, ap, in, boff, r, h, B);
     }
 }
@@ -507,6 +518,9 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
         tap_off<G, 0>(r, h, boff);
 #pragma unroll
         for (int k = 0; k + 1 < G::NBUF; ++k) load_b<G, 0>(B[k], in, boff, k);
+        // the prologue reads stay OUT of tap 0's scheduling region: inside it the (1 MFMA, 1 DS read) pattern pairs them
+        // with the MFMAs that consume them -- every MFMA of the tap then waits for the read issued right before it
+        __builtin_amdgcn_sched_barrier(0);
         run_chunks<S0, 0, G>(acc, WS, ap, in, boff, r, h, B);
     } else {
         bf16x8 b0[G::NU], b1[G::NU];
@@ -884,6 +898,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     int boff = tap_off<-1>(r, h);
     v8i b0[4], b1[4];
     load_b<0>(b0, in, boff, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prologue reads out of tap 0's scheduling region (see the bf16 kernel)
     run_taps<S0, 0>(acc, A0, A1, ap, in, boff, r, h, b0, b1);  // 9 taps: the weight set alternates, S0 ^ (tap & 1)
     BZ_STAMP(t1);
     epilogue(acc, out, second, dq, bl, w, r, h);

@@ -55,6 +55,9 @@ if has clock; then
   # in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz) and per-phase stamps of the fused net kernel
   run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16.txt" 2>&1
   FP8=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_fp8.txt" 2>&1
+  TAPS=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_taps_bf16.txt" 2>&1   # cycles per conv tap (stamped variant)
+  ZERO=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16_zero_weights.txt" 2>&1   # same instruction stream, operands that toggle nothing
+  run 300 bash tools/exp_ab_rowt.sh > "$OUT/ab_tower_rowt.txt" 2>&1            # row-tile units vs position-major, interleaved
 fi
 if has ab; then
   # cost of the in-library kernel timers on `value`, and 1 / 2 / 3 pipelines, interleaved on ONE device
