@@ -32,6 +32,7 @@ using namespace bz;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -471,7 +472,11 @@ __device__ __forceinline__ void run_chunks(f32x16 (&acc)[G::MW][G::NU], WSets<G>
 template <class G>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out, bool second,
                                          const float* __restrict__ bl, int wt0, int r, int h) {
-    const int home = G::lane_home(r) + 8 * h, swz = G::sw(r >> 3, r & 7);
+    const int swz = G::sw(r >> 3, r & 7);
+    // two opaque bases (even / odd units): every store offset is then a multiple of 512 B from its base, which lets
+    // pairs of 8-byte stores (and skip loads) go out as one ds_write2st64_b64 / ds_read2st64_b64
+    int home2[2] = {G::lane_home(r) + 8 * h, G::lane_home(r) + 8 * h + G::unit_imm(1)};
+    asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt) {
         const int wt = wt0 + mt;
@@ -479,21 +484,24 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out,
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * wt + 4 * h + 8 * q);
 #pragma unroll
-        for (int u = 0; u < G::NU; ++u) {
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int off = G::unit_imm(u) + home + (((4 * wt + q) ^ swz) << 4);
-                f32x4 v = {acc[mt][u][4 * q], acc[mt][u][4 * q + 1], acc[mt][u][4 * q + 2], acc[mt][u][4 * q + 3]};
-                v = v + bq[q];
-                if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
-                    bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
-                    v = v + __builtin_convertvector(sk, f32x4);
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int u = par; u < G::NU; u += 2) {  // units of one parity back to back: their stores pair up
+                    int off = G::unit_imm(u & ~1) + home2[par] + (((4 * wt + q) ^ swz) << 4);
+                    f32x4 v = {acc[mt][u][4 * q], acc[mt][u][4 * q + 1], acc[mt][u][4 * q + 2], acc[mt][u][4 * q + 3]};
+                    v = v + bq[q];
+                    if (second) {  // conv2 of a block writes X in place: the skip is what it overwrites
+                        bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+                        v = v + __builtin_convertvector(sk, f32x4);
+                    }
+                    // ReLU on the bf16 bit patterns: rounding keeps the sign, so max(int16 bits, 0) of the rounded value
+                    // = the rounded max(v, 0) bit for bit (-0 -> +0 included), at two packed ops per four channels
+                    s16x4 bits = __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
+                    bits = __builtin_elementwise_max(bits, (s16x4)(0));
+                    *reinterpret_cast<s16x4*>(out + off) = bits;
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.0f ? v[i] : 0.0f;
-                *reinterpret_cast<bf16x4*>(out + off) = __builtin_convertvector(v, bf16x4);
-            }
-        }
     }
 }
 

@@ -999,9 +999,9 @@ def test_net_bf16_mfma_other_widths_vs_oracle_bf16_emulation(C, NB):
     from betazero_amd.net import DeviceNet
     m = _net(C, NB, seed=7, bf16=True)
     on = orc.Net(C, NB, 64, m.flat_params())
-    dn = DeviceNet.from_module(m, 64)
+    dn = DeviceNet.from_module(m, 320)
     worst = (0.0, 0.0)
-    for n in (1, 7, 37):
+    for n in (1, 7, 37, 291):  # 291 > 256: the throughput shape (row-tile units at C = 64), ragged last workgroup
         own, opp = _positions(n, seed=20 + n)
         lg, v = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)
         olg, ov = on.forward(own, opp, bf16=True)
@@ -1013,6 +1013,11 @@ def test_net_bf16_mfma_other_widths_vs_oracle_bf16_emulation(C, NB):
     a = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)[0].cpu().numpy()
     b = dn.forward(_dev_u64(own[5:30]), _dev_u64(opp[5:30]), bf16=True)[0].cpu().numpy()
     assert np.array_equal(a[5:30].view(np.uint32), b.view(np.uint32))  # rows do not depend on their neighbours
+    own, opp = _positions(291, seed=58)   # throughput shape vs latency shape: the same bits for every row
+    big = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)
+    small = dn.forward(_dev_u64(own[100:140]), _dev_u64(opp[100:140]), bf16=True)
+    assert np.array_equal(big[0].cpu().numpy()[100:140].view(np.uint32), small[0].cpu().numpy().view(np.uint32))
+    assert np.array_equal(big[1].cpu().numpy()[100:140].view(np.uint32), small[1].cpu().numpy().view(np.uint32))
     eng = _engine("reversi", 12, 6, "net_bf16", net=dn, temp_moves=8, openings=1)
     eng.run_iteration()
     ex = eng.examples()
