@@ -33,6 +33,7 @@ using namespace bz;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -692,6 +693,9 @@ k_tower_bf16(TowerArgs T) {
     // the resident tile, then the FCs in fp32 with the position's 192 features staged in LDS (M is dead now).
     float* S = reinterpret_cast<float*>(bufM + w * 1024);  // [pf 128 | vf 64], one scratch per wave
     const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
+    bf16x8 hw[G::KC];  // all head-conv fragments in flight at once (one L2 round trip, not one per MFMA)
+#pragma unroll
+    for (int kc = 0; kc < G::KC; ++kc) hw[kc] = __builtin_bit_cast(bf16x8, T.head_wf[kc * 64 + lane]);
     for (int p = w; p < P && pos0 + p < T.n; p += 4) {
         const int pos = pos0 + p;
 #pragma unroll
@@ -700,9 +704,8 @@ k_tower_bf16(TowerArgs T) {
             const int cell = 32 * nt + r;
 #pragma unroll
             for (int kc = 0; kc < G::KC; ++kc) {
-                bf16x8 a = __builtin_bit_cast(bf16x8, T.head_wf[kc * 64 + lane]);
                 bf16x8 b = *reinterpret_cast<const bf16x8*>(bufX + p * G::TILE + G::cell_off(p, cell, 2 * kc + h));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hw[kc], b, acc, 0, 0, 0);
             }
             if (h == 0) {  // rows 0..2 of D live in registers 0..2 of lanes 0..31
                 float a0 = acc[0] + pb0, a1 = acc[1] + pb1, a2 = acc[2] + vb;
@@ -713,8 +716,9 @@ k_tower_bf16(TowerArgs T) {
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's own LDS writes have landed
         // policy FC 128 -> 65: lane a owns logit a; logit 64 (pass) is a wave reduction
+        // (the fma chains below keep their order; the unroll factors only decide how many weight loads are in flight)
         float acc = T.polfc_b[lane], part = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < 128; i += 4) {
             f32x4 s4 = *reinterpret_cast<const f32x4*>(S + i);
 #pragma unroll
@@ -728,7 +732,7 @@ k_tower_bf16(TowerArgs T) {
         float vh = 0.0f;
         if (lane < T.VH) {
             float a = T.v1_b[lane];
-#pragma unroll 4
+#pragma unroll 32
             for (int i = 0; i < 64; ++i) a = __builtin_fmaf(S[128 + i], T.v1_wT[i * T.VH + lane], a);
             vh = (a > 0.0f ? a : 0.0f) * T.v2_w[lane];
         }
@@ -869,27 +873,38 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[8], char* out, bool secon
         dqv[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q) * kActScale;
         bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q) * kActScale;
     }
-    const int home = (r >> 3) * kTile + cell_at(0, r & 7) + 4 * h, sw = sw3(r >> 3, r & 7);
+    const int sw = sw3(r >> 3, r & 7);
+    // two opaque bases (even / odd rows): every store offset is then a multiple of 256 B from its base, so pairs of
+    // 4-byte stores (and skip loads) go out as one ds_write2st64_b32 / ds_read2st64_b32
+    int home2[2] = {(r >> 3) * kTile + cell_at(0, r & 7) + 4 * h, (r >> 3) * kTile + cell_at(1, r & 7) + 4 * h};
+    asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int chunk = 2 * w + (q >> 1);
-        const int base = home + ((chunk ^ sw) << 4) + 8 * (q & 1);
+        const f32x2 dlo = {dqv[q][0], dqv[q][1]}, dhi = {dqv[q][2], dqv[q][3]};
+        const f32x2 blo = {bq[q][0], bq[q][1]}, bhi = {bq[q][2], bq[q][3]};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int off = base + u * kRowC * kCell;
-            float v[4];
+        for (int par = 0; par < 2; ++par) {
+            int base = home2[par] + ((chunk ^ sw) << 4) + 8 * (q & 1);
+            asm volatile("" : "+v"(base));  // keeps the + 8 out of the offset field (st64 offsets count 256-B steps)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(acc[u][4 * q + i], dqv[q][i], bq[q][i]);
-            if (second) {
-                int sk = *reinterpret_cast<const int*>(out + off);
-                v[0] += __builtin_amdgcn_cvt_f32_fp8(sk, 0); v[1] += __builtin_amdgcn_cvt_f32_fp8(sk, 1);
-                v[2] += __builtin_amdgcn_cvt_f32_fp8(sk, 2); v[3] += __builtin_amdgcn_cvt_f32_fp8(sk, 3);
+            for (int u = par; u < 8; u += 2) {  // rows of one parity back to back: their stores pair up
+                const int off = base + (u & ~1) * kRowC * kCell;
+                f32x2 lo = {acc[u][4 * q], acc[u][4 * q + 1]}, hi = {acc[u][4 * q + 2], acc[u][4 * q + 3]};
+                lo = __builtin_elementwise_fma(lo, dlo, blo);  // packed fp32 fma: the same roundings as four scalar fmas
+                hi = __builtin_elementwise_fma(hi, dhi, bhi);
+                if (second) {
+                    int sk = *reinterpret_cast<const int*>(out + off);
+                    lo += __builtin_amdgcn_cvt_pk_f32_fp8(sk, false);
+                    hi += __builtin_amdgcn_cvt_pk_f32_fp8(sk, true);
+                }
+                float v[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.0f, 448.0f);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                *reinterpret_cast<int*>(out + off) = pk;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], 0.0f, 448.0f);
-            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-            *reinterpret_cast<int*>(out + off) = pk;
         }
     }
 }
@@ -982,6 +997,13 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
         float* S = reinterpret_cast<float*>(bufM + p * 1024);
         const float pb0 = T.pol_b[0], pb1 = T.pol_b[1], vb = T.val_b[0];
         const float d0 = T.head_dq8[0], d1 = T.head_dq8[1], d2 = T.head_dq8[2];
+        v8i hw[2];  // both head-conv fragments in flight before the first MFMA
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 lo = T.head_wf8[(ks * 2 + 0) * 64 + lane], hi = T.head_wf8[(ks * 2 + 1) * 64 + lane];
+            v8i a = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            hw[ks] = a;
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             f32x16 acc = (f32x16)(0.0f);
@@ -989,10 +1011,8 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
             const int cb = cell_at(cell >> 3, cell & 7) + (((2 * h) ^ sw3(p, cell & 7)) << 4);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                uint4 lo = T.head_wf8[(ks * 2 + 0) * 64 + lane], hi = T.head_wf8[(ks * 2 + 1) * 64 + lane];
-                v8i a = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
                 v8i b = ld32(bufX + p * kTile, cb ^ (ks << 6), 0);
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, kUnit, 0, kUnit);
+                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hw[ks], b, acc, 0, 0, 0, kUnit, 0, kUnit);
             }
             if (h == 0) {
                 float a0 = acc[0] * d0 + pb0, a1 = acc[1] * d1 + pb1, a2 = acc[2] * d2 + vb;
@@ -1002,8 +1022,9 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
+        // (the fma chains below keep their order; the unroll factors only decide how many weight loads are in flight)
         float acc = T.polfc_b[lane], part = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
         for (int i = 0; i < 128; i += 4) {
             f32x4 s4 = *reinterpret_cast<const f32x4*>(S + i);
 #pragma unroll
@@ -1016,7 +1037,7 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
         float vh = 0.0f;
         if (lane < T.VH) {
             float a = T.v1_b[lane];
-#pragma unroll 4
+#pragma unroll 32
             for (int i = 0; i < 64; ++i) a = __builtin_fmaf(S[128 + i], T.v1_wT[i * T.VH + lane], a);
             vh = (a > 0.0f ? a : 0.0f) * T.v2_w[lane];
         }
