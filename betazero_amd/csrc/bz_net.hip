@@ -10,10 +10,12 @@
 // Two paths:
 //  * bf16 (product): the residual tower is ONE kernel (k_tower_bf16).  A
 //    workgroup of 4 waves keeps the activations of 4 positions resident in LDS
-//    (2 x 65 KB, XOR-swizzled 256-B cells, +1 zero cell per position for the
-//    conv halo) across all 2*NB conv layers; wave w owns output channels
-//    32w..32w+31 of all 4 positions (8 accumulator tiles of
-//    v_mfma_f32_32x32x16_bf16), streams its weight fragments straight from
+//    (2 x 73 KB, XOR-swizzled 256-B cells, board rows at a pitch of 9 cells
+//    with in-row zero cells for the conv halo) across all 2*NB conv layers;
+//    wave w owns output channels 32w..32w+31 of all 4 positions (8 accumulator
+//    tiles of v_mfma_f32_32x32x16_bf16 = the 8 board rows of the 4 positions,
+//    so the taps that shift by a row skip the tile that would read only
+//    padding), streams its weight fragments straight from
 //    L2 into registers in a fragment-major layout (one coalesced 1 KB load per
 //    k-step, prefetched one tap = 8 k-steps ahead) and reads the activation
 //    fragments from LDS with conflict-free ds_read_b128.  Activations never
