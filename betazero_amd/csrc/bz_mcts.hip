@@ -626,11 +626,17 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
             group_fence();
             const int rn = (int)ne;  // the root's children (>= 1: a terminal root was refused above)
             Edge re[kCH];
+            // Q = W / N and c_puct * P of the register-resident root edges are kept next to them: Q changes only for the
+            // edge a simulation backs up (one correctly rounded division per simulation instead of one per root edge),
+            // c_puct * P never.  The values are the ones puct_score would recompute, bit for bit.
+            float rq[kCH], rcp[kCH];
 #pragma unroll
             for (int k = 0; k < kCH; ++k) {
                 const int i = sub + kGW * k;
                 if (i < rn) re[k] = edges[i];
                 else { re[k].N = 0; re[k].W = 0.0f; re[k].P = 0.0f; re[k].ca = 0; }
+                rq[k] = re[k].N > 0 ? fdiv(re[k].W, (float)re[k].N) : 0.0f;
+                rcp[k] = E.c_puct * re[k].P;
             }
             for (int s = 0; s < E.sims; ++s) {
                 group_fence();  // this group's stores of the previous simulation -> its loads
@@ -641,7 +647,12 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
 #pragma unroll
                     for (int k = 0; k < kCH; ++k) {
                         int i = sub + kGW * k;
-                        float sc = i < rn ? puct_score(re[k], E.c_puct, sq) : -__builtin_inff();
+                        float sc = -__builtin_inff();
+                        if (i < rn) {  // puct_score with the cached terms
+                            float u = rcp[k] * sq;
+                            u = fdiv(u, 1.0f + (float)re[k].N);
+                            sc = rq[k] + u;
+                        }
                         float eW = re[k].W; u32 eN = re[k].N, eca = re[k].ca;
 #pragma unroll
                         for (int o = kGW / 2; o > 0; o >>= 1) {
@@ -725,6 +736,7 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                     for (int k = 0; k < kCH; ++k)
                         if (sub + kGW * k == i0) {
                             re[k].N = N0 + 1u; re[k].W = W0 + val0;
+                            rq[k] = fdiv(re[k].W, (float)re[k].N);
                             if (made && depth == 1) re[k].ca = new_ca;
                         }
                 }
