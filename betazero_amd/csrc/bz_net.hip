@@ -582,19 +582,30 @@ struct TowerArgs {
     float *logits, *value;           // [n][65], [n]
 };
 
-// stem input fragment: B[k][cell] with k = 2*tap + plane (k < 18), built from the bitboards
-__device__ __forceinline__ bf16x8 stem_frag(u64 own, u64 opp, int cell, int kbase) {
-    const int y = cell >> 3, x = cell & 7;
-    unsigned wd[4] = {0u, 0u, 0u, 0u};
+// 3x3 neighbourhood of `cell` on bitboard b: tap t = 3 (dy + 1) + (dx + 1) at bit 8 (dy + 1) + (dx + 1); cells off the
+// board read 0 (rows fall out of the 64-bit word, the two wrap-around columns are masked)
+__device__ __forceinline__ unsigned nbhd(u64 b, int cell) {
+    const int s = cell - 9;
+    const u64 w = s >= 0 ? b >> s : b << -s;
+    unsigned n = (unsigned)w & 0x00070707u;
+    const int x = cell & 7;
+    if (x == 0) n &= ~0x00010101u;  // column -1 would be the previous row's column 7
+    if (x == 7) n &= ~0x00040404u;
+    return n;
+}
+// stem input fragment: B[k][cell] with k = 2*tap + plane (k < 18), for the lane's k-group kbase = 16 KC + 8 h, from the
+// two neighbourhood words: four taps x (own, opp) as bf16 0.0 / 1.0
+template <int KC>
+__device__ __forceinline__ bf16x8 stem_frag(unsigned n_own, unsigned n_opp, int h) {
+    unsigned wd[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int k = kbase + j, tap = k >> 1;
-        int t3 = (tap * 11) >> 5;  // tap / 3 for tap < 16
-        int yy = y + t3 - 1, xx = x + (tap - 3 * t3) - 1;
-        bool inb = (unsigned)yy < 8u && (unsigned)xx < 8u && k < 18;
-        u64 brd = (j & 1) ? opp : own;  // kbase is even: plane = j & 1
-        unsigned bit = inb ? (unsigned)((brd >> ((yy * 8 + xx) & 63)) & 1ULL) : 0u;
-        wd[j >> 1] |= bit ? (0x3F80u << (16 * (j & 1))) : 0u;  // bf16 1.0
+    for (int j = 0; j < 4; ++j) {
+        constexpr int none = 31;  // bit 31 of a neighbourhood word is always 0
+        const int t0 = 8 * KC + j, t1 = t0 + 4;  // tap for h = 0 / h = 1
+        const int b0 = t0 <= 8 ? (t0 / 3) * 8 + t0 % 3 : none, b1 = t1 <= 8 ? (t1 / 3) * 8 + t1 % 3 : none;
+        const int bit = h ? b1 : b0;
+        const unsigned o = (n_own >> bit) & 1u, p = (n_opp >> bit) & 1u;
+        wd[j] = (o | (p << 16)) * 0x3F80u;  // bf16 1.0 in the low (own) / high (opp) half
     }
     uint4 u = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     return __builtin_bit_cast(bf16x8, u);
@@ -668,9 +679,9 @@ k_tower_bf16(TowerArgs T) {
 #pragma unroll
         for (int u = 0; u < G::NU; ++u) {
             const int i = G::ROWT ? 0 : u >> 1;
-            bf16x8 sf[2];
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) sf[kc] = stem_frag(own[i], opp[i], G::unit_cell(u, r), 16 * kc + 8 * h);
+            const int cell = G::unit_cell(u, r);
+            const unsigned n_own = nbhd(own[i], cell), n_opp = nbhd(opp[i], cell);
+            bf16x8 sf[2] = {stem_frag<0>(n_own, n_opp, h), stem_frag<1>(n_own, n_opp, h)};
 #pragma unroll
             for (int mt = 0; mt < MW; ++mt) {
                 acc[mt][u] = (f32x16)(0.0f);
@@ -975,11 +986,9 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
         u64 own = T.own[pos], opp = T.opp[pos];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            acc[u] = (f32x16)(0.0f);
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc], stem_frag(own, opp, 8 * u + (r & 7), 16 * kc + 8 * h),
-                                                                acc[u], 0, 0, 0);
+            const unsigned n_own = nbhd(own, 8 * u + (r & 7)), n_opp = nbhd(opp, 8 * u + (r & 7));
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0], stem_frag<0>(n_own, n_opp, h), (f32x16)(0.0f), 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[1], stem_frag<1>(n_own, n_opp, h), acc[u], 0, 0, 0);
         }
         epilogue(acc, bufX, false, T.ones, T.stem_b, w, r, h);
     }
