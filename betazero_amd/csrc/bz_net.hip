@@ -34,7 +34,9 @@ using namespace bz;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -472,9 +474,19 @@ __device__ __forceinline__ void run_chunks(f32x16 (&acc)[G::MW][G::NU], WSets<G>
 // +bias (+skip) -> ReLU -> bf16 -> LDS.  D[row = co][col = lane column r of unit u]: lane (r, h) register 4q+i of
 // M-tile wt holds co = 32wt + 8q + 4h + i of that cell, i.e. 4 consecutive channels = one 8-byte store.
 // `out` points at the wave's first position.
+// the layer's biases for the lane's channels.  Fetched BEFORE the K-loop: issued at the head of the epilogue they cost
+// it a full L2 round trip with nothing to overlap (the per-tap scheduling regions keep the compiler from hoisting them)
+template <class G> struct Bias { f32x4 q[G::MW][4]; };
+template <class G>
+__device__ __forceinline__ void load_bias(Bias<G>& b, const float* __restrict__ bl, int wt0, int h) {
+#pragma unroll
+    for (int mt = 0; mt < G::MW; ++mt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b.q[mt][q] = *reinterpret_cast<const f32x4*>(bl + 32 * (wt0 + mt) + 4 * h + 8 * q);
+}
 template <class G>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out, bool second,
-                                         const float* __restrict__ bl, int wt0, int r, int h) {
+                                         const Bias<G>& bias, int wt0, int r, int h) {
     const int swz = G::sw(r >> 3, r & 7);
     // two opaque bases (even / odd units): every store offset is then a multiple of 512 B from its base, which lets
     // pairs of 8-byte stores (and skip loads) go out as one ds_write2st64_b64 / ds_read2st64_b64
@@ -483,9 +495,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out,
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt) {
         const int wt = wt0 + mt;
-        f32x4 bq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * wt + 4 * h + 8 * q);
+        const f32x4 (&bq)[4] = bias.q[mt];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -501,9 +511,14 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out,
                     }
                     // ReLU on the bf16 bit patterns: rounding keeps the sign, so max(int16 bits, 0) of the rounded value
                     // = the rounded max(v, 0) bit for bit (-0 -> +0 included), at two packed ops per four channels
-                    s16x4 bits = __builtin_bit_cast(s16x4, __builtin_convertvector(v, bf16x4));
-                    bits = __builtin_elementwise_max(bits, (s16x4)(0));
-                    *reinterpret_cast<s16x4*>(out + off) = bits;
+                    // (two 2-element conversions: one v_cvt_pk_bf16_f32 each; the 4-element form converts every
+                    // value on its own and packs with v_perm)
+                    f32x2 vlo = {v[0], v[1]}, vhi = {v[2], v[3]};
+                    s16x2 lo = __builtin_bit_cast(s16x2, __builtin_convertvector(vlo, bf16x2));
+                    s16x2 hi = __builtin_bit_cast(s16x2, __builtin_convertvector(vhi, bf16x2));
+                    lo = __builtin_elementwise_max(lo, (s16x2)(0));
+                    hi = __builtin_elementwise_max(hi, (s16x2)(0));
+                    *reinterpret_cast<uint2*>(out + off) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
                 }
     }
 }
@@ -523,6 +538,8 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
         for (int u = 0; u < G::NU; ++u) acc[mt][u] = (f32x16)(0.0f);
     const int wpos = G::pos0(w) * G::TILE;
     in += wpos; out += wpos;
+    Bias<G> bias;
+    load_bias<G>(bias, bl, G::wt0(w), h);
     int boff[2];
     if constexpr (G::ROWT) {
         bf16x8 B[G::NBUF][G::NU];
@@ -553,7 +570,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
 #undef BZ_CHUNK
     }
     BZ_STAMP(t1);
-    epilogue<G>(acc, out, second, bl, G::wt0(w), r, h);
+    epilogue<G>(acc, out, second, bias, G::wt0(w), r, h);
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);
@@ -663,6 +680,8 @@ k_tower_bf16(TowerArgs T) {
     // ---- stem: conv3x3 2 -> C as a [C x 32] x [32 x 64] GEMM per position
     {
         f32x16 acc[MW][G::NU];
+        Bias<G> bias;
+        load_bias<G>(bias, T.stem_b, wt0, h);
         bf16x8 sa[2][MW];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
@@ -690,7 +709,7 @@ k_tower_bf16(TowerArgs T) {
                     acc[mt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[kc][mt], sf[kc], acc[mt][u], 0, 0, 0);
             }
         }
-        epilogue<G>(acc, bufX + wp0 * G::TILE, false, T.stem_b, wt0, r, h);
+        epilogue<G>(acc, bufX + wp0 * G::TILE, false, bias, wt0, r, h);
     }
     __syncthreads();
 
@@ -878,14 +897,17 @@ __device__ __forceinline__ void run_taps(f32x16 (&acc)[8], v8i (&A0)[2], v8i (&A
 // e4m3(16 * relu(acc * dq + bias (+ skip))) -> LDS, computed in the x16 domain: fma(acc, 16 dq, 16 bias)
 // (+ the stored skip code, which already is 16 x), one v_med3 for ReLU + saturation, cvt_pk.
 // lane (r, h) register 4q+i of unit u = channel 32w + 8q + 4h + i of board cell (row u, column r & 7) of position r >> 3
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[8], char* out, bool second, const float* __restrict__ dq,
-                                         const float* __restrict__ bl, int w, int r, int h) {
-    f32x4 dqv[4], bq[4];
+struct Scale { f32x4 dq[4], b[4]; };  // 16 x dequant factor and 16 x bias of the lane's channels
+__device__ __forceinline__ void load_scale(Scale& sc, const float* __restrict__ dq, const float* __restrict__ bl, int w, int h) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        dqv[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q) * kActScale;
-        bq[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q) * kActScale;
+    for (int q = 0; q < 4; ++q) {  // fetched before the K-loop (see the bf16 kernel's load_bias)
+        sc.dq[q] = *reinterpret_cast<const f32x4*>(dq + 32 * w + 4 * h + 8 * q) * kActScale;
+        sc.b[q] = *reinterpret_cast<const f32x4*>(bl + 32 * w + 4 * h + 8 * q) * kActScale;
     }
+}
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[8], char* out, bool second, const Scale& sc, int w, int r, int h) {
+    const f32x4 (&dqv)[4] = sc.dq;
+    const f32x4 (&bq)[4] = sc.b;
     const int sw = sw3(r >> 3, r & 7);
     // two opaque bases (even / odd rows): every store offset is then a multiple of 256 B from its base, so pairs of
     // 4-byte stores (and skip loads) go out as one ds_write2st64_b32 / ds_read2st64_b32
@@ -931,13 +953,15 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     f32x16 acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = (f32x16)(0.0f);
+    Scale sc;
+    load_scale(sc, dq, bl, w, h);
     int boff = tap_off<-1>(r, h);
     v8i b0[4], b1[4];
     load_b<0>(b0, in, boff, 0, 0);
     __builtin_amdgcn_sched_barrier(0);  // keep the prologue reads out of tap 0's scheduling region (see the bf16 kernel)
     run_taps<S0, 0>(acc, A0, A1, ap, in, boff, r, h, b0, b1);  // 9 taps: the weight set alternates, S0 ^ (tap & 1)
     BZ_STAMP(t1);
-    epilogue(acc, out, second, dq, bl, w, r, h);
+    epilogue(acc, out, second, sc, w, r, h);
     BZ_STAMP(t2);
     __syncthreads();
     BZ_STAMP(t3);
@@ -979,6 +1003,8 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
     // ---- stem (bf16 MFMA, exact 0/1 inputs) -> e4m3 activations
     {
         f32x16 acc[8];
+        Scale sc;
+        load_scale(sc, T.ones, T.stem_b, w, h);
         bf16x8 sa[2];
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) sa[kc] = __builtin_bit_cast(bf16x8, T.stem_wf[(kc * 4 + w) * 64 + lane]);
@@ -990,7 +1016,7 @@ __global__ void __launch_bounds__(256, 2) k_tower_fp8(TowerArgs T) {
             acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0], stem_frag<0>(n_own, n_opp, h), (f32x16)(0.0f), 0, 0, 0);
             acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[1], stem_frag<1>(n_own, n_opp, h), acc[u], 0, 0, 0);
         }
-        epilogue(acc, bufX, false, T.ones, T.stem_b, w, r, h);
+        epilogue(acc, bufX, false, sc, w, r, h);
     }
     __syncthreads();
 
