@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # BZ_HIP_SO: load a diagnostic variant built by betazero_amd.build.build_variant() instead of the
 # product library (needs BZ_ALLOW_EXPERIMENT=1 as well: such builds may time but not compute)
 SO = os.environ.get("BZ_HIP_SO") or os.path.join(HERE, "libbz_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
 GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3
@@ -26,7 +26,7 @@ class EngineCfg(C.Structure):
     _fields_ = [("game", i32), ("n_games", i32), ("sims", i32), ("eval_kind", i32), ("c_puct", C.c_float),
                 ("temp_moves", i32), ("openings", i32), ("rounds", i32), ("t_max", i32), ("stagger", i32),
                 ("seed", u64), ("game_id_base", u64), ("game_id_stride", u64),
-                ("flags", u32), ("dirichlet_alpha", C.c_float), ("dirichlet_eps", C.c_float), ("reserved", u32)]
+                ("flags", u32), ("dirichlet_alpha", C.c_float), ("dirichlet_eps", C.c_float), ("ttt_lanes", i32)]
 
 
 class EngineLayout(C.Structure):
@@ -78,6 +78,7 @@ _SIGS = {
     "bz_engine_select": (i32, [vp, u32, vp]),
     "bz_engine_evaluate": (i32, [vp, vp]),
     "bz_engine_expand_backup": (i32, [vp, vp]),
+    "bz_engine_root_noise": (i32, [vp, vp]),
     "bz_engine_root_stats": (i32, [vp, vp]),
     "bz_engine_play": (i32, [vp, i32, vp]),
     "bz_engine_status": (i32, [vp, vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]),
@@ -109,12 +110,19 @@ def lib():
         # the process has ONE HIP runtime and torch tensors / streams are valid in our kernels.
         import torch  # noqa: F401
         L = C.CDLL(SO)
+        # the version first: a stale library must fail with the rebuild message, not with an AttributeError on
+        # whichever newer symbol it happens to lack
+        ver = getattr(L, "bz_abi_version", None)
+        L_ver = None
+        if ver is not None:
+            ver.restype, ver.argtypes = _SIGS["bz_abi_version"]
+            L_ver = ver()
+        if L_ver != ABI_VERSION:
+            raise RuntimeError(f"{SO}: ABI version {L_ver}, expected {ABI_VERSION} -- rebuild it "
+                               "(python -m betazero_amd.build)")
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.bz_abi_version() != ABI_VERSION:
-            raise RuntimeError(f"{SO}: ABI version {L.bz_abi_version()}, expected {ABI_VERSION} -- rebuild it "
-                               "(python -m betazero_amd.build)")
         info = (L.bz_build_info() or b"").decode()
         if info != "product" and os.environ.get("BZ_ALLOW_EXPERIMENT") != "1":
             raise RuntimeError(f"{SO} was built with [{info}], not the product flags; refusing to load it "

@@ -2,7 +2,7 @@
 
 The product library is always built with exactly FLAGS: nothing from the environment reaches its
 compile line.  Diagnostic variants (in-kernel stamps, ...) are built by build_variant() into a
-SEPARATE file, libbz_hip.<name>.so, and are only ever loaded when BZ_HIP_SO points at them
+SEPARATE file, build/variants/libbz_hip.<name>.so (outside the package), and are only ever loaded when BZ_HIP_SO points at them
 (betazero_amd/_lib.py); they never overwrite the product library.  The flag set a library was
 built with is compiled into it (bz_build_info()) and a hash of it sits next to the .so, so a
 library built with other flags is stale no matter what its mtime says."""
@@ -30,8 +30,12 @@ def _flag_hash(extra):
     return hashlib.sha256(" ".join(FLAGS + list(extra)).encode()).hexdigest()[:16]
 
 
+VARIANT_DIR = os.path.join(HERE, "..", "build", "variants")  # git-ignored, travels to the GPU box, never inside the package
+
+
 def variant_path(name):
-    return os.path.join(HERE, f"libbz_hip.{name}.so")
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    return os.path.abspath(os.path.join(VARIANT_DIR, f"libbz_hip.{name}.so"))
 
 
 def stale(so=SO, extra=()):

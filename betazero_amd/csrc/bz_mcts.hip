@@ -3,12 +3,18 @@
 // G::GW lanes serve one game (Reversi 16, TTT 4).  Per game the tree is a bump-allocated AoS
 // pair in HBM:
 //   Node 32 B {own, opp, legal, edge0, info}     nodes[g][sims+2]
-//   Edge 16 B {N, W, P, child|action<<24}        edges[g][(sims+2)*MAXCH]
-// so one dwordx4 load brings an edge's (N, W, P, child), a node's children are one coalesced
-// block, and a backup is one 8-byte read-modify-write.  Per-game scalars are SoA across games;
-// the select path is stored depth-major path[d][g].  A simulation is two launches: k_tree_step
-// ([expand + backup of the previous leaf] + [select of the next one]) and the evaluator; leaves
-// that need the net are packed through a double-buffered device-side counter.
+//   Edge 16 B {w0, W, P, w3}                     edges[g][(sims+2)*MAXCH]
+//        w0 = N 14 | action 7 | child's edge count 6 | child terminal 1 | child's value 2
+//        w3 = child id 13 | child's first edge 19
+// One dwordx4 load brings an edge's (N, W, P) AND everything the walk needs to know about the child behind
+// it, so a level of the PUCT walk is ONE dependent load (the children's edge block) instead of node-then-
+// edges; the node array is read by the walk only for the position of the node it extends (issued beside the
+// edge load, off the chain).  The select path is stored game-major as {edge index, w0, W} as seen at
+// selection time, so the backup of the next launch is one coalesced load + one 8-byte store per edge (nothing
+// else touches a game's tree in between), and the created leaf's legal mask / header go to per-game words, so
+// the expansion does not re-read the node.  Per-game scalars are SoA across games.  A simulation is two
+// launches: k_tree_step ([expand + backup of the previous leaf] + [select of the next one]) and the evaluator;
+// leaves that need the net are packed through a double-buffered device-side counter.
 // Synthetic evaluators run the whole search in one launch (k_search_fused; k_search_fused_ttt for tic-tac-toe at
 // sims <= 120: root edges in registers, child header packed into the edge word, path in LDS).  Opt-in: Dirichlet root
 // noise (k_root_noise) and subtree reuse (two arenas, dev_reroot) -- DESIGN.md 3.9, 3.10.
@@ -21,8 +27,6 @@
 // trajectory contract tic_tac_toe.py:13-34; canonical side-to-move states
 // generate_training_games.py:12-23.  MCTS itself is build-authored (the
 // reference has none).
-#include <stdlib.h>
-
 #include <new>
 
 #include "bz_common.h"
@@ -34,8 +38,19 @@ using namespace bz;
 namespace {
 
 struct __attribute__((aligned(16))) Node { u64 own, opp, legal; u32 edge0, info; };
-struct __attribute__((aligned(16))) Edge { u32 N; float W; float P; u32 ca; };
+struct __attribute__((aligned(16))) Edge { u32 w0; float W; float P; u32 w3; };
 static_assert(sizeof(Node) == 32 && sizeof(Edge) == 16, "layout");
+// packed edge words (the limits they imply -- nodes per game <= kMaxNodes -- are checked by cfg_ok)
+constexpr int kNBits = 14, kActShift = 14, kNchShift = 21, kTermShift = 27, kValShift = 28, kChildBits = 13;
+constexpr u32 kNMask = (1u << kNBits) - 1u, kChildMask = (1u << kChildBits) - 1u;
+constexpr int kMaxNodes = (1 << kChildBits) - 1;  // also bounds N (<= nodes) and the edge index (19 bits >= 8191 * 34)
+__host__ __device__ __forceinline__ u32 e_N(u32 w0) { return w0 & kNMask; }
+__host__ __device__ __forceinline__ int e_action(u32 w0) { return (int)((w0 >> kActShift) & 0x7Fu); }
+__host__ __device__ __forceinline__ int e_nch(u32 w0) { return (int)((w0 >> kNchShift) & 0x3Fu); }
+__host__ __device__ __forceinline__ bool e_term(u32 w0) { return ((w0 >> kTermShift) & 1u) != 0; }
+__host__ __device__ __forceinline__ int e_val(u32 w0) { return (int)((w0 >> kValShift) & 3u) - 1; }
+__host__ __device__ __forceinline__ u32 e_child(u32 w3) { return w3 & kChildMask; }
+__host__ __device__ __forceinline__ u32 e_edge0(u32 w3) { return w3 >> kChildBits; }
 
 constexpr u32 kTerm = 1u << 8;
 // leaf_kind: NONE = slot idle; EVAL = the leaf awaits (logits, value); TERMINAL = backup of a terminal value;
@@ -48,6 +63,8 @@ enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDE
 enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_NEVAL = 4, FLAG_N = 8 };
 enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8 };
 
+struct __attribute__((aligned(16))) PathEnt { u32 eidx; u32 w0; float W; u32 pad; };
+
 struct EngineDev {
     int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd, stagger;
     int compact;  // net evaluators: leaves needing evaluation are packed (c_own/c_opp/logits/value by slot)
@@ -57,8 +74,9 @@ struct EngineDev {
     u64 seed, id_base, id_stride;
     Node* nodes; Edge* edges;
     u64 *g_own, *g_opp; int8_t* g_to_move; uint8_t* g_state; int32_t *g_moves, *g_nex, *g_round, *g_passes;
-    u32 *n_nodes, *n_edges, *path, *depth, *leaf_node;
-    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp, *c_own, *c_opp; u32* leaf_slot;
+    u32 *n_nodes, *n_edges, *depth, *leaf_node, *leaf_info, *root_n;
+    PathEnt* path;  // [B][maxd], game-major
+    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp, *leaf_legal, *c_own, *c_opp; u32* leaf_slot;
     float *logits, *value;
     u64 *ex_own, *ex_opp; float* ex_pi; int8_t *ex_z, *ex_mover; uint8_t* ex_act; int32_t* ex_len; int8_t* ex_winner;
     u32* root_N; float *root_W, *root_P;
@@ -67,18 +85,96 @@ struct EngineDev {
 
 struct Cnt { u32 v[CNT_N]; };
 
-// counters are accumulated per wave into that wave's own slot (plain read-modify-write, no
-// atomics: 1000+ waves hammering 8 shared addresses cost more than the tree walk itself);
+// Diagnostic build only (betazero_amd.build.build_variant("treestamps", ["-DBZ_EXP_TREE_STAMPS"]), tools/exp_tree_stamps.py):
+// shader-clock stamps between the phases of k_tree_step, summed over all waves into counters[8..15].  The product build
+// compiles the empty struct away.
+#ifdef BZ_EXP_TREE_STAMPS
+#ifndef BZ_EXPERIMENT
+#error "BZ_EXP_TREE_STAMPS is a diagnostic option: build it through betazero_amd.build.build_variant()"
+#endif
+struct Stamps {
+    u64 last; u32 acc[8];
+    __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void mark(int k) { const u64 now = __builtin_readcyclecounter(); acc[k] += (u32)(now - last); last = now; }
+    __device__ __forceinline__ void flush(u64* counters) {
+        if ((threadIdx.x & 63) == 0) {
+            for (int k = 0; k < 7; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(counters) + 8 + k, (unsigned long long)acc[k]);
+            atomicAdd(reinterpret_cast<unsigned long long*>(counters) + 15, 1ULL);  // waves
+        }
+    }
+};
+#else
+struct Stamps {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(u64*) {}
+};
+#endif
+
+// ---- lane exchange inside a lane group (kGW <= 16 lanes = at most one DPP row): butterfly partner for step O,
+// valid when the steps run in ASCENDING order (1, 2, 4, 8): 1 and 2 are quad permutes, 4 / 8 the half-row / row
+// mirrors (the lower levels are uniform by then, so the mirror image is the partner half).  DPP moves are VALU
+// operations; the ds_bpermute a generic shuffle compiles to is an LDS round trip.
+template <int O>
+__device__ __forceinline__ int xchg_i(int x) {
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8, "butterfly step");
+    constexpr int ctrl = O == 1 ? 0xB1 : (O == 2 ? 0x4E : (O == 4 ? 0x141 : 0x140));
+    return __builtin_amdgcn_update_dpp(0, x, ctrl, 0xF, 0xF, true);
+}
+template <int O> __device__ __forceinline__ u32 xchg(u32 x) { return (u32)xchg_i<O>((int)x); }
+template <int O> __device__ __forceinline__ int xchg(int x) { return xchg_i<O>(x); }
+template <int O> __device__ __forceinline__ float xchg(float x) { return __int_as_float(xchg_i<O>(__float_as_int(x))); }
+// value of the previous lane of the row (lane 0 of a row: 0)
+__device__ __forceinline__ float row_shr1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xF, 0xF, true));
+}
+
+// PUCT candidates: first maximum (lowest child index on ties) over the kGW lanes of a group
+struct Cand { float sc; int i; u32 w0, w3; float W; };
+template <int O>
+__device__ __forceinline__ void cand_step(Cand& c) {
+    const float s2 = xchg<O>(c.sc), W2 = xchg<O>(c.W); const int i2 = xchg<O>(c.i);
+    const u32 a2 = xchg<O>(c.w0), b2 = xchg<O>(c.w3);
+    const bool take = (s2 > c.sc) || (s2 == c.sc && i2 < c.i);
+    if (take) { c.sc = s2; c.i = i2; c.w0 = a2; c.w3 = b2; c.W = W2; }
+}
+template <int kGW>
+__device__ __forceinline__ void group_argmax(Cand& c) {
+    if (kGW > 1) cand_step<1>(c);
+    if (kGW > 2) cand_step<2>(c);
+    if (kGW > 4) cand_step<4>(c);
+    if (kGW > 8) cand_step<8>(c);
+}
+template <int kGW>
+__device__ __forceinline__ float group_max(float m) {
+    if (kGW > 1) { float m2 = xchg<1>(m); m = m2 > m ? m2 : m; }
+    if (kGW > 2) { float m2 = xchg<2>(m); m = m2 > m ? m2 : m; }
+    if (kGW > 4) { float m2 = xchg<4>(m); m = m2 > m ? m2 : m; }
+    if (kGW > 8) { float m2 = xchg<8>(m); m = m2 > m ? m2 : m; }
+    return m;
+}
+
+// counters are accumulated by the lead lane of every lane group and flushed per wave into that wave's own slot
+// (1000+ waves hammering 8 shared addresses cost more than the tree walk itself): the leads' counts are summed
+// across the groups, then lanes 0..7 each add ONE counter with an atomic that returns nothing -- nothing waits
+// for it (eight load -> wait -> store sequences at the end of every wave were a fifth of the tree step's time).
 // k_sum_counters folds the slots into counters[16] when the host asks.
+template <int kGW>
 __device__ __forceinline__ void cnt_flush(const EngineDev& E, Cnt& c) {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = (int)(threadIdx.x & 63);
+    u32 mine = 0;
 #pragma unroll
     for (int k = 0; k < CNT_N; ++k) {
         u32 x = c.v[k];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        if ((threadIdx.x & 63) == 0 && x && wave < (u32)E.n_cnt_slots) E.cnt_slots[(size_t)wave * CNT_N + k] += x;
+        for (int o = 32; o >= kGW; o >>= 1) x += __shfl_xor(x, o, 64);  // (lanes that are not leads hold zeros)
+        x = (u32)__builtin_amdgcn_readfirstlane((int)x);                 // lane 0 is a lead: it holds the wave's sum
+        mine = lane == k ? x : mine;
     }
+    if (lane < CNT_N && mine && wave < (u32)E.n_cnt_slots)
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(E.cnt_slots) + (size_t)wave * CNT_N + lane,
+                               (unsigned long long)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void __launch_bounds__(256) k_sum_counters(EngineDev E) {
@@ -102,17 +198,25 @@ __global__ void __launch_bounds__(256) k_sum_counters(EngineDev E) {
 // so no s_waitcnt vmcnt(0) (a full store round trip, which a workgroup-scope fence costs) is needed.
 __device__ __forceinline__ void group_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// where the select walk records its path (edge index + that edge's N and W at selection time, so
-// that the backup is a pure store): HBM, depth-major across games, for the step-by-step kernels
-// whose backup runs in a later launch; LDS for the fused search.
-struct PathEnt { u32 eidx; u32 N; float W; };
-struct PathHbm {
-    const EngineDev& E; int g;
-    __device__ __forceinline__ void put(int d, u32 eidx, u32, float) const { E.path[(size_t)d * E.B + g] = eidx; }
+// where the select walk records its path: edge index + that edge's w0 (N and the child header) and W as the walk
+// saw / left them, so that the backup is a pure store.  HBM, game-major (a game's entries are one coalesced load for
+// its lane group), for the step-by-step kernels whose backup runs in the next launch; LDS for the fused search.
+// (every lane of the group calls put() with the same arguments)
+template <int kGW>
+struct PathHbm {  // lane d of the group keeps entry d in registers during the walk -- no store, so nothing for the next
+    PathEnt* p;   // level's load to queue behind -- and writes it at the end (one coalesced store per game); levels
+    PathEnt mine; // beyond the group width (rare) go to memory directly
+    __device__ __forceinline__ void put(int d, int sub, u32 eidx, u32 w0, float W) {
+        if (d < kGW) { if (sub == d) { mine.eidx = eidx; mine.w0 = w0; mine.W = W; } }
+        else if (sub == 0) { PathEnt e; e.eidx = eidx; e.w0 = w0; e.W = W; e.pad = 0; p[d] = e; }
+    }
+    __device__ __forceinline__ void flush(int sub, int depth) const { if (sub < depth && sub < kGW) p[sub] = mine; }
 };
 struct PathLds {
     PathEnt* p;  // this game's MAXD entries
-    __device__ __forceinline__ void put(int d, u32 eidx, u32 N, float W) const { PathEnt e; e.eidx = eidx; e.N = N; e.W = W; p[d] = e; }
+    __device__ __forceinline__ void put(int d, int sub, u32 eidx, u32 w0, float W) const {
+        if (sub == 0) { PathEnt e; e.eidx = eidx; e.w0 = w0; e.W = W; e.pad = 0; p[d] = e; }
+    }
 };
 
 // logits source for the expansion of one leaf
@@ -123,92 +227,93 @@ struct LogitSrc {
     }
 };
 
-// ---- cooperative tree walk: G::GW lanes serve one game (Reversi 16 -> 4 games per wave, TTT 8 -> 8
+// ---- cooperative tree walk: G::GW lanes serve one game (Reversi 16 -> 4 games per wave, TTT 4 -> 16
 // games per wave: the walk is a dependent chain per game, so games in flight = memory-level
-// parallelism).  A level of the
-// PUCT walk is one broadcast node load + one coalesced 256-byte load of up to 16 edges, the
+// parallelism).  A level of the PUCT walk is one coalesced 256-byte load of up to 16 edges (the chosen
+// edge's words say where the child's edges are, how many, and whether the child is terminal), the
 // scores are computed one child per lane and reduced with 4 shuffle steps (first maximum, i.e.
 // lowest action on ties); softmax terms are computed one legal move per lane, but SUMMED in
 // ascending action order by a serial shuffle scan so that the result is bit-identical to the
 // sequential spec; the backup updates one path edge per lane.
 
+// what the walk starts from: the root's position, mover colour and child count (its edges start at index 0)
+struct RootRef { u64 own, opp; int tm; int n; u32 sumN; };
+// the node select created (valid when a child was created)
+struct LeafPos { u64 own, opp, legal; u32 info; };
+
 // M2: PUCT walk from the root; creates the child node behind the chosen unexpanded edge (env step:
 // apply + legal + terminal).  All lanes of the group return the same values.
-struct LeafPos { u64 own, opp, legal; u32 info; };  // the node select created (valid when kind != terminal-revisit)
-
 template <class G, class Sink>
-__device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u32 sim_idx, u32& n_nodes_g,
+__device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, const RootRef& root, u32& n_nodes_g,
                                            u32& leaf, int& kind, int& depth_out, float& tval, Cnt& c,
-                                           const Sink& sink, LeafPos& lp) {
+                                           Sink& sink, LeafPos& lp, Stamps& st) {
     constexpr int kGW = G::GW;
     Node* nodes = E.nodes + (size_t)g * E.ncap;
     Edge* edges = E.edges + (size_t)g * E.ecap;
     // sum of the root's child visits == simulations done so far (+ the visits a kept subtree came with)
-    u32 node = 0, sumN = sim_idx + (E.reuse ? E.g_root_base[g] : 0u);
-    int depth = 0;
+    u32 e0 = 0, sumN = root.sumN;
+    int n = root.n, depth = 0;
+    u64 pown = root.own, popp = root.opp;  // position of the node whose edges are being scored
     const bool lead = sub == 0;
-    if (lead) c.v[CNT_SIMS]++;
+    if (lead) { c.v[CNT_SIMS]++; c.v[CNT_PATH_NODES]++; }
     for (;;) {
-        Node nd = nodes[node];
-        if (lead) c.v[CNT_PATH_NODES]++;
-        if (nd.info & kTerm) {
-            kind = LEAF_TERMINAL; leaf = node; tval = (float)((int)((nd.info >> 9) & 3u) - 1);
-            break;
-        }
-        const int n = (int)(nd.info & 0xFFu);
         const float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
-        const Edge* ed = edges + nd.edge0;
-        float bests = -__builtin_inff(), bestW = 0.0f; int best = 0; u32 bestN = 0, bestca = 0;
+        const Edge* ed = edges + e0;
+        float bests = -__builtin_inff(), bestW = 0.0f; int best = 0; u32 bestw0 = 0, bestw3 = 0;
         for (int base = 0; base < n; base += kGW) {
-            int i = base + sub;
-            float sc = -__builtin_inff(), eW = 0.0f; u32 eN = 0, eca = 0;
-            if (i < n) {
-                Edge e = ed[i];
-                float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
+            Cand cd; cd.i = base + sub; cd.sc = -__builtin_inff(); cd.W = 0.0f; cd.w0 = 0; cd.w3 = 0;
+            if (cd.i < n) {
+                Edge e = ed[cd.i];
+                const u32 N = e_N(e.w0);
+                float q = N > 0 ? fdiv(e.W, (float)N) : 0.0f;
                 float u = E.c_puct * e.P;
                 u = u * sq;
-                u = fdiv(u, 1.0f + (float)e.N);
-                sc = q + u; eN = e.N; eca = e.ca; eW = e.W;
+                u = fdiv(u, 1.0f + (float)N);
+                cd.sc = q + u; cd.w0 = e.w0; cd.w3 = e.w3; cd.W = e.W;
             }
-#pragma unroll
-            for (int o = kGW / 2; o > 0; o >>= 1) {
-                float s2 = __shfl_xor(sc, o, kGW), w2 = __shfl_xor(eW, o, kGW); int i2 = __shfl_xor(i, o, kGW);
-                u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
-                bool take = (s2 > sc) || (s2 == sc && i2 < i);
-                if (take) { sc = s2; i = i2; eN = n2; eca = c2; eW = w2; }
-            }
-            if (sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; bestW = eW; }
+            group_argmax<kGW>(cd);
+            if (cd.sc > bests) { bests = cd.sc; best = cd.i; bestw0 = cd.w0; bestw3 = cd.w3; bestW = cd.W; }
         }
         if (lead) c.v[CNT_CHILD_SCORED] += (u32)n;
-        u32 eidx = nd.edge0 + (u32)best;
-        if (lead) {
-            if (depth < E.maxd) sink.put(depth, eidx, bestN, bestW);
-            else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
-        }
-        depth++;
-        u32 child = bestca & 0xFFFFFFu;
-        if (child) {  // children's visits of X == visits of the edge into X minus the creating one
-            node = child; sumN = bestN - 1u;
+        const u32 eidx = e0 + (u32)best;
+        const u32 child = e_child(bestw3);
+        if (child) {
+            if (lead) c.v[CNT_PATH_NODES]++;
+            if (depth < E.maxd) sink.put(depth, sub, eidx, bestw0, bestW);
+            else if (lead) atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
+            depth++;
+            if (e_term(bestw0)) { kind = LEAF_TERMINAL; leaf = child; tval = (float)e_val(bestw0); break; }
+            // children's visits of X == visits of the edge into X minus the creating one
+            e0 = e_edge0(bestw3); n = e_nch(bestw0); sumN = e_N(bestw0) - 1u;
+            // X's position is needed only if the walk ends by extending X: the load goes out beside X's edge load
+            const Node* xn = nodes + child;
+            pown = xn->own; popp = xn->opp;
             continue;
         }
-        int act = (int)(bestca >> 24);
+        st.mark(3);
+        const int act = e_action(bestw0);
         u64 cown, copp;
-        G::apply(nd.own, nd.opp, act, &cown, &copp);
-        u32 id = n_nodes_g++;
-        int tm = ((nd.info >> 11) & 1u) ? -1 : 1;  // child's mover = the other colour
+        G::apply(pown, popp, act, &cown, &copp);
+        const u32 id = n_nodes_g++;
+        const int tm = (depth & 1) ? root.tm : -root.tm;  // child's mover: the colours alternate down the walk (passes included)
         u64 lg = G::legal(cown, copp);
         int tv = 0;
-        bool term = G::terminal(cown, copp, tm, lg, &tv);
+        const bool term = G::terminal(cown, copp, tm, lg, &tv);
         lp.own = cown; lp.opp = copp; lp.legal = term ? 0 : lg;
         lp.info = (term ? kTerm : 0u) | ((u32)(tv + 1) << 9) | ((tm == 1 ? 1u : 0u) << 11);
+        const u32 w0 = bestw0 | ((term ? 1u : 0u) << kTermShift) | ((u32)(tv + 1) << kValShift);
         if (lead) {
             Node ch;
             ch.own = cown; ch.opp = copp; ch.legal = lp.legal; ch.edge0 = 0; ch.info = lp.info;
             nodes[id] = ch;
-            edges[eidx].ca = id | ((u32)act << 24);
+            edges[eidx].w0 = w0; edges[eidx].w3 = id;  // (the child's first edge / edge count follow with its expansion)
             c.v[CNT_ENV_STEPS]++; c.v[CNT_PATH_NODES]++;
         }
+        if (depth < E.maxd) sink.put(depth, sub, eidx, w0, bestW);
+        else if (lead) atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
+        depth++;
         leaf = id; kind = term ? LEAF_TERMINAL : LEAF_EVAL; tval = (float)tv;
+        st.mark(4);
         break;
     }
     depth_out = depth;
@@ -216,16 +321,29 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, u
 
 // k-th (0-based) set bit of m, or -1
 __device__ __forceinline__ int nth_bit(u64 m, int k) {
-    for (int j = 0; j < k; ++j) m &= m - 1;
-    return m ? ctz64(m) : -1;
+    if (k >= popc64(m)) return -1;
+    u32 w = (u32)m;
+    int pos = 0, c = __popc(w);
+    if (k >= c) { k -= c; w = (u32)(m >> 32); pos = 32; }
+    c = __popc(w & 0xFFFFu); if (k >= c) { k -= c; w >>= 16; pos += 16; }
+    c = __popc(w & 0xFFu);   if (k >= c) { k -= c; w >>= 8;  pos += 8; }
+    c = __popc(w & 0xFu);    if (k >= c) { k -= c; w >>= 4;  pos += 4; }
+    c = __popc(w & 0x3u);    if (k >= c) { k -= c; w >>= 2;  pos += 2; }
+    return pos + (k >= (int)(w & 1u) ? 1 : 0);
 }
+
+// how dev_expand writes a fresh edge: the engine's packed record, or the private record of the tic-tac-toe
+// fused search (plain N in word 0, its own child header in word 3)
+struct EdgeFmtPacked { static __device__ __forceinline__ Edge make(float P, int a) { Edge e; e.w0 = (u32)a << kActShift; e.W = 0.0f; e.P = P; e.w3 = 0; return e; } };
+struct EdgeFmtTttFused { static __device__ __forceinline__ Edge make(float P, int a) { Edge e; e.w0 = 0; e.W = 0.0f; e.P = P; e.w3 = (u32)a << 24; return e; } };
 
 // M3: masked softmax over the legal actions (ascending), edges bump-allocated.  `legal` is the
 // leaf's legal mask (known to the caller: the root's or the node select just created).
 // `info` = the leaf's header word as created (child count 0): the header is rewritten, never re-read.
-template <class G, int kGW = G::GW, bool kHeader = true>
-__device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info,
-                                           const LogitSrc& ls, u32& n_edges_g, Cnt& c) {
+// Returns the number of edges written (they start at the old n_edges_g).
+template <class G, int kGW = G::GW, bool kHeader = true, class Fmt = EdgeFmtPacked>
+__device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info,
+                                          const LogitSrc& ls, u32& n_edges_g, Cnt& c, Stamps& st) {
     constexpr int kCH = (G::MAXCH + kGW - 1) / kGW;
     Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
     const u32 e0 = n_edges_g;
@@ -234,7 +352,7 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
     int n = 0;
     if (legal == 0) {  // forced pass: one edge, P = 1
         if (room >= 1) {
-            if (sub == 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = 1.0f; e.ca = (u32)kPass << 24; ed[0] = e; }
+            if (sub == 0) ed[0] = Fmt::make(1.0f, kPass);
             n = 1;
         }
     } else {
@@ -249,21 +367,33 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
             x[k] = a[k] >= 0 ? ls(a[k]) : -__builtin_inff();
             m = x[k] > m ? x[k] : m;
         }
-#pragma unroll
-        for (int o = kGW / 2; o > 0; o >>= 1) { float m2 = __shfl_xor(m, o, kGW); m = m2 > m ? m2 : m; }
+        m = group_max<kGW>(m);
+        st.mark(1);  // (the evaluator's row has arrived)
         float ex[kCH];
 #pragma unroll
         for (int k = 0; k < kCH; ++k) ex[k] = a[k] >= 0 ? expf_spec(x[k] - m) : 0.0f;
-        float s = 0.0f;  // ascending-action serial sum (the spec's order), every lane computes it
+        // ascending-action serial sum (the spec's order): the partial sum travels up the group one lane per step
+        // (lane t adds its own term to what lane t-1 holds), every step one DPP add; lanes past the last move hold
+        // +0.0, which leaves a positive sum unchanged, so the chain runs its full length without tests.
+        float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < kCH; ++k)
-            for (int j = 0; j < kGW && kGW * k + j < n; ++j) s = s + __shfl(ex[k], j, kGW);
+        for (int k = 0; k < kCH; ++k) {
+            if (kGW * k < n) {
+                float part = s + ex[k];  // (lane 0's is the true partial sum; the others are overwritten below)
+#pragma unroll
+                for (int t = 1; t < kGW; ++t) {
+                    const float cand = row_shr1(part) + ex[k];
+                    part = sub == t ? cand : part;
+                }
+                s = __shfl(part, kGW - 1, kGW);
+            }
+        }
         float pr[kCH];
 #pragma unroll
         for (int k = 0; k < kCH; ++k) pr[k] = a[k] >= 0 ? fdiv(ex[k], s) : 0.0f;
 #pragma unroll
         for (int k = 0; k < kCH; ++k)
-            if (a[k] >= 0) { Edge e; e.N = 0; e.W = 0.0f; e.P = pr[k]; e.ca = (u32)a[k] << 24; ed[sub + kGW * k] = e; }
+            if (a[k] >= 0) ed[sub + kGW * k] = Fmt::make(pr[k], a[k]);
     }
     if (sub == 0) {
         if (kHeader) *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);  // edge0, info: one 8-byte store
@@ -271,33 +401,32 @@ __device__ __forceinline__ void dev_expand(const EngineDev& E, int g, int sub, u
         c.v[CNT_CHILD_WRITTEN] += (u32)n;
     }
     n_edges_g = e0 + (u32)n;
+    return n;
 }
 
-// M4: W is stored for the mover at the parent, so the sign flips every ply; one path edge per lane
-// fused search: N and W of every path edge were captured by the select walk (nothing else touches this
-// game's tree in between), so the backup is one 8-byte store per path edge, no load
-template <int kGW>
-__device__ __forceinline__ void dev_backup_lds(const EngineDev& E, int g, int sub, int depth, float v, const PathEnt* path, Cnt& c) {
-    Edge* edges = E.edges + (size_t)g * E.ecap;
-    const int dmax = depth < E.maxd ? depth : E.maxd;
-    for (int d = sub; d < dmax; d += kGW) {
-        PathEnt pe = path[d];
-        float val = ((dmax - 1 - d) & 1) ? v : -v;  // deepest edge gets -v
-        *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(pe.N + 1u, __float_as_uint(pe.W + val));
+// M4: W is stored for the mover at the parent, so the sign flips every ply; one path edge per lane.
+// N and W of every path edge were captured by the select walk (nothing else touches this game's tree
+// in between), so the backup is one 8-byte store per path edge and reads nothing but the path.  The
+// deepest edge leads to the leaf: when the leaf was expanded just now (exp_n > 0 edges from exp_e0),
+// its edge count / first edge go into that edge's words with the same stores.
+__device__ __forceinline__ void backup_edge(Edge* edges, const PathEnt& pe, float val, bool deepest, u32 leaf, u32 exp_e0, int exp_n) {
+    u32 w0 = pe.w0 + 1u;
+    if (deepest && exp_n > 0) {
+        w0 |= (u32)exp_n << kNchShift;
+        edges[pe.eidx].w3 = leaf | (exp_e0 << kChildBits);
     }
-    if (sub == 0) c.v[CNT_EDGES_BACKED] += (u32)dmax;
+    *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(w0, __float_as_uint(pe.W + val));
 }
 
 template <int kGW>
-__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, Cnt& c) {
+__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, const PathEnt* path,
+                                           u32 leaf, u32 exp_e0, int exp_n, Cnt& c) {
     Edge* edges = E.edges + (size_t)g * E.ecap;
     const int dmax = depth < E.maxd ? depth : E.maxd;
     for (int d = sub; d < dmax; d += kGW) {
-        Edge* e = edges + E.path[(size_t)d * E.B + g];
-        float val = ((dmax - 1 - d) & 1) ? v : -v;  // deepest edge gets -v
-        u32 N = e->N; float W = e->W;
-        e->N = N + 1u;
-        e->W = W + val;
+        const PathEnt pe = path[d];
+        const float val = ((dmax - 1 - d) & 1) ? v : -v;  // deepest edge gets -v
+        backup_edge(edges, pe, val, d == depth - 1, leaf, exp_e0, exp_n);
     }
     if (sub == 0) c.v[CNT_EDGES_BACKED] += (u32)dmax;
 }
@@ -314,6 +443,7 @@ __device__ __forceinline__ bool dev_root_init(const EngineDev& E, int g) {
     }
     Node r; r.own = own; r.opp = opp; r.legal = lg; r.edge0 = 0; r.info = (tm == 1 ? 1u : 0u) << 11;
     E.nodes[(size_t)g * E.ncap] = r;
+    E.leaf_legal[g] = lg; E.leaf_info[g] = r.info;  // what the expansion of this "leaf" reads
     return true;
 }
 
@@ -393,17 +523,23 @@ __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_ro
     Edge* de = E.edges + (size_t)g * E.ecap;
     u32 n_dst = 1, e_dst = 0;
     dn[0] = sn[src_root];
+    // nodes are laid out in breadth-first order and so are their edge blocks: the first edge of the node that gets
+    // id k is the number of edges of all nodes before it, known the moment k is handed out
+    u32 e_next = dn[0].info & 0xFFu;
+    E.root_n[g] = e_next;
     for (u32 i = 0; i < n_dst; ++i) {
         Node nd = dn[i];  // edge0 still points into the source arena
         if (nd.info & kTerm) continue;
         const u32 n = nd.info & 0xFFu, s0 = nd.edge0;
         for (u32 j = 0; j < n; ++j) {
             Edge e = se[s0 + j];
-            const u32 child = e.ca & 0xFFFFFFu;
+            const u32 child = e_child(e.w3);
             if (child) {
                 const u32 id = n_dst++;
-                dn[id] = sn[child];
-                e.ca = id | (e.ca & 0xFF000000u);
+                const Node cn = sn[child];
+                dn[id] = cn;
+                e.w3 = id | (e_next << kChildBits);
+                e_next += cn.info & 0xFFu;  // (0 for terminal / not yet expanded nodes)
             }
             de[e_dst + j] = e;
         }
@@ -473,49 +609,80 @@ __global__ void __launch_bounds__(256) k_eval_synth(EngineDev E, int eval_kind) 
 
 // One tree step for every game (16 lanes per game): [expand + backup of the previous leaf] and/or
 // [select of the next leaf].  With a net in the loop a simulation is exactly two launches:
-// this kernel and the net.
+// this kernel and the net.  The kernel is a dependent-access chain per game (every game of the launch is
+// in flight at once), so its time is the number of memory round trips on the longest chain: one for all
+// per-game words and the path (independent loads), one for the evaluator's row, then one per level of the walk.
+// keeps a loaded value "used" at this point of the program: the loads above it cannot be sunk into the branches
+// that consume them, so they go out back to back and complete in ONE memory round trip
+template <class T> __device__ __forceinline__ void pin(T& x) { asm volatile("" : "+v"(x)); }
+
 template <class G>
 __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, int do_select, u32 sim_idx) {
     constexpr int kGW = G::GW;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
     Cnt c = {};
+    Stamps st; st.start();
+    // packed-leaf slots: ONE atomic on the shared counter per workgroup.  Same-address atomics are served one after the
+    // other (~10 ns each): one per wave -- 1024 per launch at 4096 games -- was half of this kernel's time.
+    __shared__ u32 s_need, s_base;
+    if (threadIdx.x == 0) s_need = 0;
+    __syncthreads();
+    bool want_slot = false; u32 my_rank = 0; u64 slot_own = 0, slot_opp = 0;
     if (g < E.B) {
-        int kind = E.leaf_kind[g];
-        const bool active = E.g_state[g] == 0 && kind != LEAF_NONE;
+        PathEnt* path = E.path + (size_t)g * E.maxd;
+        // ---- round trip 1: every per-game word this step can need + the first kGW path entries, all independent
+        int kind = E.leaf_kind[g], state = E.g_state[g];
+        u32 leaf = E.leaf_node[g], ninfo = E.leaf_info[g], ne = E.n_edges[g], nn = E.n_nodes[g], row = (u32)g;
+        if (E.compact) row = E.leaf_slot[g];
+        int depth0 = (int)E.depth[g], root_n = (int)E.root_n[g], rtm = E.g_to_move[g];
+        u64 nlegal = E.leaf_legal[g], rown = E.g_own[g], ropp = E.g_opp[g];
+        u32 root_base = 0;
+        if (E.reuse) root_base = E.g_root_base[g];
+        PathEnt pe0 = path[sub];  // (maxd >= kGW for every game)
+        pin(kind); pin(state); pin(leaf); pin(ninfo); pin(ne); pin(nn); pin(row); pin(depth0); pin(root_n); pin(rtm);
+        pin(nlegal); pin(rown); pin(ropp); pin(root_base); pin(pe0.eidx); pin(pe0.w0); pin(pe0.W);
+        const bool active = state == 0 && kind != LEAF_NONE;
+        st.mark(0);
         if (do_expand && (kind == LEAF_EVAL || kind == LEAF_TERMINAL)) {
-            u32 leaf = E.leaf_node[g];
-            const Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
-            const u64 nlegal = nd->legal; const u32 ninfo = nd->info;
             float v;
-            if (kind == LEAF_EVAL) {
-                u32 ne = E.n_edges[g];
-                size_t row = E.compact ? (size_t)E.leaf_slot[g] : (size_t)g;
-                LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + row * G::NA;
-                dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c);
-                if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; }
+            u32 e0 = ne; int n = 0;
+            if (kind == LEAF_EVAL) {  // ---- round trip 2: the evaluator's row
+                LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + (size_t)row * G::NA;
                 v = E.value[row];
+                n = dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c, st);
+                if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.root_n[g] = (u32)n; }
+                if (leaf == 0) root_n = n;
             } else {
                 v = (float)((int)((ninfo >> 9) & 3u) - 1);
             }
-            dev_backup<G::GW>(E, g, sub, (int)E.depth[g], v, c);
+            // backup: path entries 0..kGW-1 are in registers already; deeper walks (rare) load theirs
+            Edge* edges = E.edges + (size_t)g * E.ecap;
+            const int dmax = depth0 < E.maxd ? depth0 : E.maxd;
+            if (sub < dmax) backup_edge(edges, pe0, ((dmax - 1 - sub) & 1) ? v : -v, sub == depth0 - 1, leaf, e0, n);
+            for (int d = sub + kGW; d < dmax; d += kGW)
+                backup_edge(edges, path[d], ((dmax - 1 - d) & 1) ? v : -v, d == depth0 - 1, leaf, e0, n);
+            if (sub == 0) c.v[CNT_EDGES_BACKED] += (u32)dmax;
         }
+        st.mark(2);
         if (do_select) {
             uint8_t kind8 = LEAF_NONE;
             if (active) {
                 group_fence();  // edges written above are read below
-                u32 nn = E.n_nodes[g], leaf; int k2, depth; float tv;
+                u32 leaf2; int k2, depth; float tv;
                 LeafPos lpos; lpos.own = 0; lpos.opp = 0; lpos.legal = 0; lpos.info = 0;
-                PathHbm sink{E, g};
-                dev_select<G>(E, g, sub, sim_idx, nn, leaf, k2, depth, tv, c, sink, lpos);
+                RootRef root; root.own = rown; root.opp = ropp; root.tm = rtm; root.n = root_n;
+                root.sumN = sim_idx + root_base;
+                PathHbm<kGW> sink; sink.p = path; sink.mine.eidx = 0; sink.mine.w0 = 0; sink.mine.W = 0.0f; sink.mine.pad = 0;
+                dev_select<G>(E, g, sub, root, nn, leaf2, k2, depth, tv, c, sink, lpos, st);  // ---- one round trip per level
+                sink.flush(sub, depth);
                 if (sub == 0) {
-                    E.n_nodes[g] = nn; E.leaf_node[g] = leaf; E.depth[g] = (u32)depth;
+                    E.n_nodes[g] = nn; E.leaf_node[g] = leaf2; E.depth[g] = (u32)depth;
                     if (k2 == LEAF_EVAL) {  // only an evaluated leaf's position is consumed (evaluator input)
-                        E.leaf_own[g] = lpos.own; E.leaf_opp[g] = lpos.opp;
-                        if (E.compact) {
-                            u32 slot = atomicAdd(&E.flags[FLAG_NEVAL + (sim_idx & 1u)], 1u);
-                            E.leaf_slot[g] = slot; E.c_own[slot] = lpos.own; E.c_opp[slot] = lpos.opp;
-                        }
+                        E.leaf_own[g] = lpos.own; E.leaf_opp[g] = lpos.opp; E.leaf_legal[g] = lpos.legal; E.leaf_info[g] = lpos.info;
+                        if (E.compact) { want_slot = true; my_rank = atomicAdd(&s_need, 1u); slot_own = lpos.own; slot_opp = lpos.opp; }
+                    } else {  // terminal leaf (new or revisited): the backup needs its value only
+                        E.leaf_info[g] = (u32)((int)tv + 1) << 9;
                     }
                 }
                 kind8 = (uint8_t)k2;
@@ -526,7 +693,19 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
             E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0;
         }
     }
-    cnt_flush(E, c);
+    if (do_select && E.compact) {  // (kernel arguments: the whole grid takes this branch or none of it)
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_need ? atomicAdd(&E.flags[FLAG_NEVAL + (sim_idx & 1u)], s_need) : 0u;
+        __syncthreads();
+        if (want_slot) {
+            const u32 slot = s_base + my_rank;
+            E.leaf_slot[g] = slot; E.c_own[slot] = slot_own; E.c_opp[slot] = slot_opp;
+        }
+    }
+    st.mark(5);
+    cnt_flush<G::GW>(E, c);
+    st.mark(6);
+    st.flush(E.counters);
 }
 
 // whole search in one launch for the synthetic evaluators (BASELINE cfg 2):
@@ -551,28 +730,32 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
         if (ok) {
             u32 nn = 1, ne = 0;
             LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
-            const u64 rown = E.g_own[g], ropp = E.g_opp[g];
-            ls.h = hash_pos(rown, ropp);
+            RootRef root; root.own = E.g_own[g]; root.opp = E.g_opp[g]; root.tm = E.g_to_move[g];
+            ls.h = hash_pos(root.own, root.opp);
             group_fence();
-            dev_expand<G>(E, g, sub, 0, G::legal(rown, ropp), (E.g_to_move[g] == 1 ? 1u : 0u) << 11, ls, ne, c);
+            Stamps st; st.start();
+            root.n = dev_expand<G>(E, g, sub, 0, G::legal(root.own, root.opp), (root.tm == 1 ? 1u : 0u) << 11, ls, ne, c, st);
+            if (sub == 0) E.root_n[g] = (u32)root.n;
             PathLds sink{mypath};
             for (int s = 0; s < E.sims; ++s) {
                 group_fence();  // this group's stores -> its loads
                 u32 leaf; int kind, depth; float v;
                 LeafPos lp; lp.own = 0; lp.opp = 0; lp.legal = 0; lp.info = 0;
-                dev_select<G>(E, g, sub, (u32)s, nn, leaf, kind, depth, v, c, sink, lp);
+                root.sumN = (u32)s;
+                dev_select<G>(E, g, sub, root, nn, leaf, kind, depth, v, c, sink, lp, st);
+                u32 e0 = ne; int n = 0;
                 if (kind == LEAF_EVAL) {
                     ls.h = hash_pos(lp.own, lp.opp);
-                    dev_expand<G>(E, g, sub, leaf, lp.legal, lp.info, ls, ne, c);
+                    n = dev_expand<G>(E, g, sub, leaf, lp.legal, lp.info, ls, ne, c, st);
                     v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
                 }
                 group_fence();  // LDS path entries (lane 0) -> the lanes that back them up
-                dev_backup_lds<G::GW>(E, g, sub, depth, v, mypath, c);
+                dev_backup<G::GW>(E, g, sub, depth, v, mypath, leaf, e0, n, c);
             }
             if (sub == 0) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
         }
     }
-    cnt_flush(E, c);
+    cnt_flush<G::GW>(E, c);
 }
 
 // ---- Tic-tac-toe specialisation of the fused search (BASELINE cfg 2; sims <= 120).
@@ -582,21 +765,22 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
 //    of every simulation reads nothing, its backup writes nothing; the edges go to HBM once, at the end;
 //  * an edge's `ca` word also carries what the walk needs to know about the child -- its first edge, its
 //    child count, terminal flag and value -- so a level is ONE load (the child's edges), never the child's
-//    node first (TTT's numbers fit in 32 bits: child 8 | edge0 12 | n 4 | action 4 | terminal 1 | value 2);
+//    node first (TTT's numbers fit in ONE word: child 8 | edge0 12 | n 4 | action 4 | terminal 1 | value 2 in w3,
+//    with w0 a plain visit count -- this kernel's private edge record, EdgeFmtTttFused);
 //  * positions are carried down the walk by applying the actions (TTT: swap + one bit), so nodes below the
 //    root are never loaded -- and, since nothing reads them, never stored.
 // Results (root statistics, counters, examples) are bit-identical to the generic kernel and the oracle; the
-// root edges are written back in the generic format, which is all that k_play / k_root_stats read.
+// root edges are written back as the engine's packed record, which is all that k_play / k_root_stats read.
 __device__ __forceinline__ u32 ttt_ca(u32 child, u32 edge0, u32 n, u32 act, bool term, int tv) {
     return child | (edge0 << 8) | (n << 20) | (act << 24) | ((term ? 1u : 0u) << 28) | ((u32)(tv + 1) << 29);
 }
 constexpr int kTttFusedMaxSims = 120;
 
 __device__ __forceinline__ float puct_score(const Edge& e, float c_puct, float sq) {
-    float q = e.N > 0 ? fdiv(e.W, (float)e.N) : 0.0f;
+    float q = e.w0 > 0 ? fdiv(e.W, (float)e.w0) : 0.0f;
     float u = c_puct * e.P;
     u = u * sq;
-    u = fdiv(u, 1.0f + (float)e.N);
+    u = fdiv(u, 1.0f + (float)e.w0);
     return q + u;
 }
 
@@ -622,7 +806,8 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
             const int rtm = E.g_to_move[g];
             ls.h = hash_pos(rown, ropp);
             group_fence();
-            dev_expand<G, kGW, true>(E, g, sub, 0, G::legal(rown, ropp), (rtm == 1 ? 1u : 0u) << 11, ls, ne, c);
+            Stamps st; st.start();
+            dev_expand<G, kGW, true, EdgeFmtTttFused>(E, g, sub, 0, G::legal(rown, ropp), (rtm == 1 ? 1u : 0u) << 11, ls, ne, c, st);
             group_fence();
             const int rn = (int)ne;  // the root's children (>= 1: a terminal root was refused above)
             Edge re[kCH];
@@ -634,8 +819,8 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
             for (int k = 0; k < kCH; ++k) {
                 const int i = sub + kGW * k;
                 if (i < rn) re[k] = edges[i];
-                else { re[k].N = 0; re[k].W = 0.0f; re[k].P = 0.0f; re[k].ca = 0; }
-                rq[k] = re[k].N > 0 ? fdiv(re[k].W, (float)re[k].N) : 0.0f;
+                else { re[k].w0 = 0; re[k].W = 0.0f; re[k].P = 0.0f; re[k].w3 = 0; }
+                rq[k] = re[k].w0 > 0 ? fdiv(re[k].W, (float)re[k].w0) : 0.0f;
                 rcp[k] = E.c_puct * re[k].P;
             }
             for (int s = 0; s < E.sims; ++s) {
@@ -650,18 +835,12 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                         float sc = -__builtin_inff();
                         if (i < rn) {  // puct_score with the cached terms
                             float u = rcp[k] * sq;
-                            u = fdiv(u, 1.0f + (float)re[k].N);
+                            u = fdiv(u, 1.0f + (float)re[k].w0);
                             sc = rq[k] + u;
                         }
-                        float eW = re[k].W; u32 eN = re[k].N, eca = re[k].ca;
-#pragma unroll
-                        for (int o = kGW / 2; o > 0; o >>= 1) {
-                            float s2 = __shfl_xor(sc, o, kGW), w2 = __shfl_xor(eW, o, kGW); int i2 = __shfl_xor(i, o, kGW);
-                            u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
-                            bool take = (s2 > sc) || (s2 == sc && i2 < i);
-                            if (take) { sc = s2; i = i2; eN = n2; eca = c2; eW = w2; }
-                        }
-                        if (sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; bestW = eW; }
+                        Cand cd; cd.sc = sc; cd.i = i; cd.w0 = re[k].w0; cd.w3 = re[k].w3; cd.W = re[k].W;
+                        group_argmax<kGW>(cd);
+                        if (cd.sc > bests) { bests = cd.sc; best = cd.i; bestN = cd.w0; bestca = cd.w3; bestW = cd.W; }
                     }
                 }
                 if (lead) { c.v[CNT_SIMS]++; c.v[CNT_PATH_NODES]++; c.v[CNT_CHILD_SCORED] += (u32)rn; }
@@ -686,22 +865,15 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                         bests = -__builtin_inff(); best = 0; bestN = 0; bestca = 0; bestW = 0.0f;
 #pragma unroll
                         for (int k = 0; k < kCH; ++k) {
-                            int i = sub + kGW * k;
-                            float sc = -__builtin_inff(), eW = 0.0f; u32 eN = 0, eca = 0;
-                            if (i < n) { Edge e = ed[i]; sc = puct_score(e, E.c_puct, sq); eN = e.N; eca = e.ca; eW = e.W; }
-#pragma unroll
-                            for (int o = kGW / 2; o > 0; o >>= 1) {
-                                float s2 = __shfl_xor(sc, o, kGW), w2 = __shfl_xor(eW, o, kGW); int i2 = __shfl_xor(i, o, kGW);
-                                u32 n2 = __shfl_xor(eN, o, kGW), c2 = __shfl_xor(eca, o, kGW);
-                                bool take = (s2 > sc) || (s2 == sc && i2 < i);
-                                if (take) { sc = s2; i = i2; eN = n2; eca = c2; eW = w2; }
-                            }
-                            if (kGW * k < n && sc > bests) { bests = sc; best = i; bestN = eN; bestca = eca; bestW = eW; }
+                            Cand cd; cd.i = sub + kGW * k; cd.sc = -__builtin_inff(); cd.W = 0.0f; cd.w0 = 0; cd.w3 = 0;
+                            if (cd.i < n) { Edge e = ed[cd.i]; cd.sc = puct_score(e, E.c_puct, sq); cd.w0 = e.w0; cd.w3 = e.w3; cd.W = e.W; }
+                            group_argmax<kGW>(cd);
+                            if (kGW * k < n && cd.sc > bests) { bests = cd.sc; best = cd.i; bestN = cd.w0; bestca = cd.w3; bestW = cd.W; }
                         }
                         pe_idx = e0 + (u32)best;
                         if (lead) {
                             c.v[CNT_CHILD_SCORED] += (u32)n;
-                            if (depth < E.maxd) { PathEnt pe; pe.eidx = pe_idx; pe.N = bestN; pe.W = bestW; mypath[depth] = pe; }
+                            if (depth < E.maxd) { PathEnt pe; pe.eidx = pe_idx; pe.w0 = bestN; pe.W = bestW; pe.pad = 0; mypath[depth] = pe; }
                             else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
                         }
                         depth++;
@@ -720,14 +892,14 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                     } else {
                         ls.h = hash_pos(own, opp);
                         const u32 e0 = ne;
-                        dev_expand<G, kGW, false>(E, g, sub, id, lg, 0, ls, ne, c);
+                        dev_expand<G, kGW, false, EdgeFmtTttFused>(E, g, sub, id, lg, 0, ls, ne, c, st);
                         new_ca = ttt_ca(id, e0, ne - e0, (u32)act, false, 0);
                         v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
                     }
                     made = true;
                     break;
                 }
-                if (made && depth > 1 && lead) edges[pe_idx].ca = new_ca;  // (depth 1: the parent edge is a root register)
+                if (made && depth > 1 && lead) edges[pe_idx].w3 = new_ca;  // (depth 1: the parent edge is a root register)
                 // ---- backup: root edge in registers, deeper edges by one 8-byte store each from the LDS path
                 const int dmax = depth < E.maxd ? depth : E.maxd;
                 {
@@ -735,9 +907,9 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
 #pragma unroll
                     for (int k = 0; k < kCH; ++k)
                         if (sub + kGW * k == i0) {
-                            re[k].N = N0 + 1u; re[k].W = W0 + val0;
-                            rq[k] = fdiv(re[k].W, (float)re[k].N);
-                            if (made && depth == 1) re[k].ca = new_ca;
+                            re[k].w0 = N0 + 1u; re[k].W = W0 + val0;
+                            rq[k] = fdiv(re[k].W, (float)re[k].w0);
+                            if (made && depth == 1) re[k].w3 = new_ca;
                         }
                 }
                 group_fence();  // the lead lane's LDS path entries -> the lanes that back them up
@@ -745,20 +917,20 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                     if (d == 0) continue;
                     PathEnt pe = mypath[d];
                     float val = ((dmax - 1 - d) & 1) ? v : -v;
-                    *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(pe.N + 1u, __float_as_uint(pe.W + val));
+                    *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(pe.w0 + 1u, __float_as_uint(pe.W + val));
                 }
                 if (lead) c.v[CNT_EDGES_BACKED] += (u32)dmax;
             }
-            // root edges back to HBM in the generic format (child | action << 24): what k_play / k_root_stats read
+            // root edges back to HBM as the engine's packed record (N | action, child id): what k_play / k_root_stats read
 #pragma unroll
             for (int k = 0; k < kCH; ++k) {
                 const int i = sub + kGW * k;
-                if (i < rn) { Edge e = re[k]; e.ca = (e.ca & 0xFFu) | (((e.ca >> 24) & 0xFu) << 24); edges[i] = e; }
+                if (i < rn) { Edge e = re[k]; e.w0 = e.w0 | (((e.w3 >> 24) & 0xFu) << kActShift); e.w3 = e.w3 & 0xFFu; edges[i] = e; }
             }
-            if (lead) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
+            if (lead) { E.n_nodes[g] = nn; E.n_edges[g] = ne; E.root_n[g] = (u32)rn; }
         }
     }
-    cnt_flush(E, c);
+    cnt_flush<kGW>(E, c);
 }
 
 template <class G>
@@ -772,8 +944,8 @@ __global__ void __launch_bounds__(256) k_root_stats(EngineDev E) {
     const Edge* ed = E.edges + (size_t)g * E.ecap + r.edge0;
     for (int i = 0; i < (int)(r.info & 0xFFu); ++i) {
         Edge e = ed[i];
-        int a = (int)(e.ca >> 24);
-        rn[a] = e.N; rw[a] = e.W; rp[a] = e.P;
+        int a = e_action(e.w0);
+        rn[a] = e_N(e.w0); rw[a] = e.W; rp[a] = e.P;
     }
 }
 
@@ -787,7 +959,7 @@ __global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
     const Edge* ed = E.edges + (size_t)g * E.ecap + root.edge0;
     int n = (int)(root.info & 0xFFu);
     u32 sumN = 0;
-    for (int i = 0; i < n; ++i) sumN += ed[i].N;
+    for (int i = 0; i < n; ++i) sumN += e_N(ed[i].w0);
     int round = E.g_round[g], nex = E.g_nex[g], made = E.g_moves[g], tm = E.g_to_move[g];
     size_t rowbase = ((size_t)round * E.B + g) * E.t_max;
     if (nex >= E.t_max) { atomicOr(&E.flags[FLAG_ERR], ERR_EXAMPLE_OVERFLOW); E.g_state[g] = 1; return; }
@@ -800,21 +972,22 @@ __global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
         u64 rr = rng_draw(E.seed, gid, (u64)made) % (u64)sumN, cum = 0;
         bool found = false;
         for (int i = 0; i < n; ++i) {
-            u32 N = ed[i].N;
-            pi[ed[i].ca >> 24] = fdiv((float)N, (float)sumN);
+            const u32 w0 = ed[i].w0, N = e_N(w0);
+            pi[e_action(w0)] = fdiv((float)N, (float)sumN);
             cum += N;
             if (!found && cum > rr) { pick = i; found = true; }
         }
     } else {  // tau = 0: argmax N, ties -> lowest action
         u32 bn = 0;
         for (int i = 0; i < n; ++i) {
-            u32 N = ed[i].N;
-            pi[ed[i].ca >> 24] = fdiv((float)N, (float)sumN);
+            const u32 w0 = ed[i].w0, N = e_N(w0);
+            pi[e_action(w0)] = fdiv((float)N, (float)sumN);
             if (N > bn) { bn = N; pick = i; }
         }
     }
-    int a = (int)(ed[pick].ca >> 24);
-    u32 keep_node = ed[pick].ca & 0xFFFFFFu, keep_N = ed[pick].N;  // subtree reuse: the chosen child and its visits
+    const Edge pk = ed[pick];
+    int a = e_action(pk.w0);
+    u32 keep_node = e_child(pk.w3), keep_N = e_N(pk.w0);  // subtree reuse: the chosen child and its visits
     E.ex_own[row] = root.own; E.ex_opp[row] = root.opp; E.ex_mover[row] = (int8_t)tm; E.ex_act[row] = (uint8_t)a;
     nex++;
     u64 own, opp;
@@ -836,7 +1009,7 @@ __global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
         if (E.reuse && keep_node) {  // the kept root lies behind the child's only edge, the pass
             const Node cn = E.nodes[(size_t)g * E.ncap + keep_node];
             const Edge pe = E.edges[(size_t)g * E.ecap + cn.edge0];
-            keep_node = pe.ca & 0xFFFFFFu; keep_N = pe.N;
+            keep_node = e_child(pe.w3); keep_N = e_N(pe.w0);
         }
     }
     if (E.reuse) {  // keep the subtree iff it exists and the next search cannot outgrow the arena
@@ -865,7 +1038,7 @@ struct bz_engine {
     bz_net* net;
     int64_t bytes;
     int pack_parity;  // which NEVAL buffer the last root_begin / select packed into
-    int ttt_gw;       // lanes per game of the TTT-specialised fused search (4; BZ_TTT_GW=2|4|8 for tuning runs, 0 = generic kernel)
+    int ttt_gw;       // lanes per game of the TTT-specialised fused search (cfg.ttt_lanes; 0 = the generic any-game kernel)
 };
 
 namespace {
@@ -876,17 +1049,26 @@ struct Carver {
 
 struct Offsets {
     int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_root_base, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
-        path, depth, leaf_node, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
+        path, depth, leaf_node, leaf_info, root_n, leaf_kind, leaf_own, leaf_opp, leaf_legal, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
         ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, total;
     int n_cnt_slots;
     int ncap, ecap, na, maxd;
 };
 
+// nodes a game's arena holds: a fresh tree grows by one node per simulation; with subtree reuse a kept
+// subtree + sims new nodes must fit
+inline int64_t nodes_per_game(const bz_engine_cfg& c) { return ((c.flags & BZ_ENGINE_REUSE_SUBTREE) ? 4 : 1) * ((int64_t)c.sims + 2); }
+
 bool cfg_ok(const bz_engine_cfg* c) {
-    return c && c->game >= BZ_GAME_TTT && c->game <= BZ_GAME_REVERSI4 && c->n_games > 0 && c->sims >= 1 &&
-           c->sims < (1 << 20) && c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_NET_FP8 && c->rounds >= 1 &&
-           c->t_max >= 1 && c->dirichlet_eps >= 0.0f && c->dirichlet_eps <= 1.0f &&
-           (c->dirichlet_eps == 0.0f || (c->dirichlet_alpha > 0.0f && c->dirichlet_alpha <= 1.0f));
+    if (!(c && c->game >= BZ_GAME_TTT && c->game <= BZ_GAME_REVERSI4 && c->n_games > 0 && c->sims >= 1 &&
+          c->eval_kind >= 0 && c->eval_kind <= BZ_EVAL_NET_FP8 && c->rounds >= 1 &&
+          c->t_max >= 1 && c->dirichlet_eps >= 0.0f && c->dirichlet_eps <= 1.0f &&
+          (c->dirichlet_eps == 0.0f || (c->dirichlet_alpha > 0.0f && c->dirichlet_alpha <= 1.0f)) &&
+          (c->ttt_lanes == -1 || c->ttt_lanes == 0 || c->ttt_lanes == 1 || c->ttt_lanes == 2 || c->ttt_lanes == 4 ||
+           c->ttt_lanes == 8)))
+        return false;
+    // the packed edge record holds node ids in 13 bits and visit counts in 14 (BZ_ENGINE_MAX_SIMS in bz_abi.h)
+    return nodes_per_game(*c) <= kMaxNodes;
 }
 
 Offsets carve(const bz_engine_cfg& c) {
@@ -895,7 +1077,7 @@ Offsets carve(const bz_engine_cfg& c) {
     o.na = ttt ? TicTacToe::NA : Reversi::NA;
     o.maxd = ttt ? TicTacToe::MAXD : Reversi::MAXD;
     const bool reuse = (c.flags & BZ_ENGINE_REUSE_SUBTREE) != 0;
-    o.ncap = (reuse ? 4 : 1) * (c.sims + 2);  // a kept subtree + sims new nodes must fit
+    o.ncap = (int)nodes_per_game(c);
     o.ecap = o.ncap * (ttt ? TicTacToe::MAXCH : Reversi::MAXCH);
     int64_t B = c.n_games, R = c.rounds, T = c.t_max;
     Carver k;
@@ -907,8 +1089,9 @@ Offsets carve(const bz_engine_cfg& c) {
     o.g_own = k.take(B * 8); o.g_opp = k.take(B * 8); o.g_to_move = k.take(B); o.g_state = k.take(B);
     o.g_moves = k.take(B * 4); o.g_nex = k.take(B * 4); o.g_round = k.take(B * 4); o.g_passes = k.take(B * 4);
     o.n_nodes = k.take(B * 4); o.n_edges = k.take(B * 4);
-    o.path = k.take((int64_t)o.maxd * B * 4); o.depth = k.take(B * 4); o.leaf_node = k.take(B * 4);
-    o.leaf_kind = k.take(B); o.leaf_own = k.take(B * 8); o.leaf_opp = k.take(B * 8);
+    o.path = k.take((int64_t)o.maxd * B * (int64_t)sizeof(PathEnt)); o.depth = k.take(B * 4); o.leaf_node = k.take(B * 4);
+    o.leaf_info = k.take(B * 4); o.root_n = k.take(B * 4);
+    o.leaf_kind = k.take(B); o.leaf_own = k.take(B * 8); o.leaf_opp = k.take(B * 8); o.leaf_legal = k.take(B * 8);
     o.c_own = k.take(B * 8); o.c_opp = k.take(B * 8); o.leaf_slot = k.take(B * 4);
     o.logits = k.take(B * o.na * 4); o.value = k.take(B * 4);
     o.ex_own = k.take(R * B * T * 8); o.ex_opp = k.take(R * B * T * 8); o.ex_pi = k.take(R * B * T * o.na * 4);
@@ -947,13 +1130,16 @@ inline dim3 grid_lane(int B, int) { return grid_of(B); }
 #define BZ_DISPATCH(e, KERNEL, stream, ...) BZ_DISPATCH_IMPL(e, KERNEL, grid_lane, stream, __VA_ARGS__)
 #define BZ_DISPATCH_G(e, KERNEL, stream, ...) BZ_DISPATCH_IMPL(e, KERNEL, grid_groups, stream, __VA_ARGS__)
 
+const char* kBadCfg = "bad config (note: sims <= 8189, or <= 2045 with BZ_ENGINE_REUSE_SUBTREE -- the packed edge record, bz_abi.h)";
+
 BZ_EXPORT int64_t bz_engine_workspace_bytes(const bz_engine_cfg* cfg) {
-    if (!cfg_ok(cfg)) { set_error("bz_engine_workspace_bytes: bad config"); return -1; }
+    if (!cfg_ok(cfg)) { set_error("bz_engine_workspace_bytes: %s", kBadCfg); return -1; }
     return carve(*cfg).total;
 }
 
 BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t bytes, bz_engine** out) {
-    BZ_REQUIRE(cfg_ok(cfg) && ws && out, "bz_engine_create: bad config or null pointer");
+    BZ_REQUIRE(ws && out, "bz_engine_create: null pointer");
+    if (!cfg_ok(cfg)) { set_error("bz_engine_create: %s", kBadCfg); return BZ_EINVAL; }
     if (bz_device_count() <= 0) { set_error("bz_engine_create: no HIP device (the engine has no CPU path)"); return BZ_ENOGPU; }
     Offsets o = carve(*cfg);
     if (bytes < o.total) { set_error("bz_engine_create: workspace too small (%lld < %lld)", (long long)bytes, (long long)o.total); return BZ_ENOMEM; }
@@ -963,8 +1149,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1;
     // measured on MI355X at 65,536 games x 50 sims (profiles/r02_cfg2_*): 2 lanes 0.185 ms, 4 lanes 0.190 ms, 8 lanes
     // 0.294 ms per launch; small batches keep 4 lanes so that the chip still sees a few waves per CU
-    e->ttt_gw = cfg->n_games >= 32768 ? 2 : 4;
-    if (const char* gw = getenv("BZ_TTT_GW")) { int v = atoi(gw); if (v == 0 || v == 1 || v == 2 || v == 4 || v == 8) e->ttt_gw = v; }
+    e->ttt_gw = cfg->ttt_lanes > 0 ? cfg->ttt_lanes : (cfg->ttt_lanes < 0 ? 0 : (cfg->n_games >= 32768 ? 2 : 4));
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
@@ -977,9 +1162,10 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.g_own = at<u64>(ws, o.g_own); d.g_opp = at<u64>(ws, o.g_opp); d.g_to_move = at<int8_t>(ws, o.g_to_move);
     d.g_state = at<uint8_t>(ws, o.g_state); d.g_moves = at<int32_t>(ws, o.g_moves); d.g_nex = at<int32_t>(ws, o.g_nex);
     d.g_round = at<int32_t>(ws, o.g_round); d.g_passes = at<int32_t>(ws, o.g_passes);
-    d.n_nodes = at<u32>(ws, o.n_nodes); d.n_edges = at<u32>(ws, o.n_edges); d.path = at<u32>(ws, o.path);
+    d.n_nodes = at<u32>(ws, o.n_nodes); d.n_edges = at<u32>(ws, o.n_edges); d.path = at<PathEnt>(ws, o.path);
     d.depth = at<u32>(ws, o.depth); d.leaf_node = at<u32>(ws, o.leaf_node); d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
-    d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
+    d.leaf_info = at<u32>(ws, o.leaf_info); d.root_n = at<u32>(ws, o.root_n);
+    d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp); d.leaf_legal = at<u64>(ws, o.leaf_legal);
     d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp); d.leaf_slot = at<u32>(ws, o.leaf_slot);
     d.compact = (cfg->eval_kind == BZ_EVAL_NET_F32 || cfg->eval_kind == BZ_EVAL_NET_BF16 ||
                  cfg->eval_kind == BZ_EVAL_NET_FP8) ? 1 : 0;
@@ -1096,6 +1282,16 @@ BZ_EXPORT int32_t bz_engine_expand_backup(bz_engine* e, void* stream) {
     return tree_step(e, 1, 0, 0, stream);
 }
 
+/* Dirichlet noise on the priors of every active slot's (expanded) root; a no-op when cfg.dirichlet_eps == 0.
+ * Step-API order: root_begin, evaluate, expand_backup, root_noise, then select(0) ... -- what bz_engine_search does. */
+BZ_EXPORT int32_t bz_engine_root_noise(bz_engine* e, void* stream) {
+    BZ_REQUIRE(e, "null engine");
+    if (!(e->dev.dir_eps > 0.0f)) return BZ_OK;
+    hipLaunchKernelGGL(k_root_noise, dim3((e->dev.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->dev);
+    BZ_LAUNCH_CHECK("k_root_noise");
+    return BZ_OK;
+}
+
 BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     int ek = e->cfg.eval_kind;
@@ -1122,8 +1318,7 @@ BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
     if ((rc = bz_engine_evaluate(e, stream)) != BZ_OK) return rc;
     if (noise) {  // expand the roots on their own, then draw the noise, then start selecting
         if ((rc = tree_step(e, 1, 0, 0, stream)) != BZ_OK) return rc;
-        hipLaunchKernelGGL(k_root_noise, dim3((e->dev.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->dev);
-        BZ_LAUNCH_CHECK("k_root_noise");
+        if ((rc = bz_engine_root_noise(e, stream)) != BZ_OK) return rc;
     }
     for (int s = 0; s < e->cfg.sims; ++s) {  // expand+backup of leaf s-1 (s = 0: the root) fused with select s
         if ((rc = tree_step(e, (noise && s == 0) ? 0 : 1, 1, (uint32_t)s, stream)) != BZ_OK) return rc;

@@ -55,7 +55,7 @@ class Examples:
 class SelfPlayEngine:
     def __init__(self, game, n_games, sims, evaluator="uniform", net=None, c_puct=1.5, temp_moves=0, openings=0,
                  seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0", stagger=0,
-                 dirichlet_alpha=0.0, dirichlet_eps=0.0, reuse_subtree=False):
+                 dirichlet_alpha=0.0, dirichlet_eps=0.0, reuse_subtree=False, ttt_lanes=0):
         _lib.require_gpu()
         L = _lib.lib()
         self.game = _GAMES[game]
@@ -63,7 +63,7 @@ class SelfPlayEngine:
         t_max = 9 if self.game == GAME_TTT else 64
         self.cfg = EngineCfg(self.game, n_games, sims, _EVALS[evaluator], c_puct, temp_moves, openings, rounds, t_max,
                              stagger, seed, game_id_base, n_games if game_id_stride is None else game_id_stride,
-                             _lib.ENGINE_REUSE_SUBTREE if reuse_subtree else 0, dirichlet_alpha, dirichlet_eps, 0)
+                             _lib.ENGINE_REUSE_SUBTREE if reuse_subtree else 0, dirichlet_alpha, dirichlet_eps, ttt_lanes)
         nbytes = L.bz_engine_workspace_bytes(C.byref(self.cfg))
         if nbytes < 0:
             raise RuntimeError(_lib.last_error())
@@ -121,11 +121,17 @@ class SelfPlayEngine:
             lb["logits"].copy_(lg.to(torch.float32).reshape(lb["logits"].shape))
             lb["value"].copy_(v.to(torch.float32).reshape(lb["value"].shape))
         self.root_begin(); fill(); self.expand_backup()
+        self.root_noise()  # (no-op unless dirichlet_eps > 0) same place as in bz_engine_search
         for s in range(self.sims):
             self.select(s); fill(); self.expand_backup()
 
     def root_begin(self):
         self._call(_lib.lib().bz_engine_root_begin)
+
+    def root_noise(self):
+        """Dirichlet noise on the expanded roots' priors (no-op when dirichlet_eps == 0); step-API callers run it
+        after the expand_backup() that follows root_begin() and before select(0)"""
+        self._call(_lib.lib().bz_engine_root_noise)
 
     def select(self, sim_index):
         self._call(_lib.lib().bz_engine_select, sim_index)

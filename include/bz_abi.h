@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 2
+#define BZ_ABI_VERSION 3
 
 enum { BZ_OK = 0, BZ_EINVAL = 1, BZ_EILLEGAL_MOVE = 2, BZ_EHIP = 3, BZ_ENOMEM = 4, BZ_ENOGPU = 5,
        BZ_ESTATE = 6 };
@@ -208,8 +208,16 @@ typedef struct bz_engine_cfg {
     float dirichlet_alpha;   /* 0 < alpha <= 1 when dirichlet_eps > 0 */
     float dirichlet_eps;     /* > 0: root priors P' = (1 - eps) P + eps Dirichlet(alpha), a fresh draw per
                               * search keyed by (seed, game id, moves made) -- DESIGN.md 3.9 */
-    uint32_t reserved;
+    int32_t ttt_lanes;       /* tic-tac-toe fused search (synthetic evaluators, sims <= 120): lanes that serve one game --
+                              * 0 = default (2 at >= 32,768 games, else 4), 1 / 2 / 4 / 8 = as given, -1 = the generic
+                              * any-game fused kernel.  Results are identical for every setting. */
 } bz_engine_cfg;
+/* The tree's edge record packs (visits 14 bits | action | the child's edge count, terminal flag and value) and
+ * (child id 13 bits | the child's first edge 19 bits) into two words, so a game's tree holds at most 8191 nodes:
+ * sims <= 8189, or <= 2045 with BZ_ENGINE_REUSE_SUBTREE (the arena then holds 4 x (sims + 2) nodes).  Larger
+ * values are refused with BZ_EINVAL. */
+#define BZ_ENGINE_MAX_SIMS 8189
+#define BZ_ENGINE_MAX_SIMS_REUSE 2045
 /* keep the chosen child's subtree as the next search's tree; searches then go through the
  * step kernels for every evaluator */
 #define BZ_ENGINE_REUSE_SUBTREE 1u
@@ -257,6 +265,10 @@ int32_t bz_engine_root_begin(bz_engine* e, void* stream);   /* roots -> leaf buf
 int32_t bz_engine_select(bz_engine* e, uint32_t sim_index, void* stream); /* M2: PUCT walk + env step */
 int32_t bz_engine_evaluate(bz_engine* e, void* stream);     /* run cfg.eval_kind on leaves */
 int32_t bz_engine_expand_backup(bz_engine* e, void* stream);/* M3 + M4                     */
+/* Dirichlet root noise (cfg.dirichlet_eps > 0; a no-op otherwise) on the priors of the expanded roots.  Step-API
+ * callers run it once per search, after the expand_backup that follows root_begin and before select(0) -- the order
+ * bz_engine_search uses. */
+int32_t bz_engine_root_noise(bz_engine* e, void* stream);
 /* copy root edge statistics into the root_N/W/P arrays, indexed by action */
 int32_t bz_engine_root_stats(bz_engine* e, void* stream);
 /* M5: pi, move choice, example row, env step, pass rule, terminal handling.

@@ -200,8 +200,8 @@ def test_search_random_reversi_positions_vs_oracle():
 
 
 # ---------------------------------------------------------------- self-play
-def _check_selfplay(game, n, sims, ev, temp_moves, openings, seed, base=0, net=None, onet=None):
-    eng = _engine(game, n, sims, ev, net=net, temp_moves=temp_moves, openings=openings, seed=seed, game_id_base=base)
+def _check_selfplay(game, n, sims, ev, temp_moves, openings, seed, base=0, net=None, onet=None, **kw):
+    eng = _engine(game, n, sims, ev, net=net, temp_moves=temp_moves, openings=openings, seed=seed, game_id_base=base, **kw)
     eng.run_iteration()
     ex = eng.examples()
     winners, lens = eng.winners()
@@ -954,24 +954,24 @@ def test_reversi_score_batch_counts_vs_oracle():
         assert (ws, nx, no) == (int(w[i]), int(c[i, 0]), int(c[i, 1]))
 
 
-@pytest.mark.parametrize("gw", ["2", "4", "8"])
-def test_ttt_specialised_fused_search_equals_generic_kernel_and_oracle(gw, monkeypatch):
+@pytest.mark.parametrize("gw", [1, 2, 4, 8])
+def test_ttt_specialised_fused_search_equals_generic_kernel_and_oracle(gw):
     """the TTT-specialised fused search (root edges in registers, child header packed into the edge word, no
-    node loads below the root; lanes per game = 2, 4 or 8) against the generic fused kernel (BZ_TTT_GW=0) and the
-    oracle: root N/W/P, every work counter and complete games, bit for bit, from random reachable positions"""
+    node loads below the root; lanes per game = cfg.ttt_lanes = 1, 2, 4 or 8) against the generic fused kernel
+    (ttt_lanes = -1) and the oracle: root N/W/P, every work counter and complete games, bit for bit, from random
+    reachable positions"""
     d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
     pos = d["pos"]
     live = pos[pos[:, 4] == 0]  # not game-over
-    rng = np.random.default_rng(int(gw))
+    rng = np.random.default_rng(gw)
     sel = live[rng.choice(len(live), 500, replace=False)]
     tm = np.where(sel[:, 2] == 1, 1, -1).astype(np.int8)
     own = np.where(tm == 1, sel[:, 0], sel[:, 1]).astype(np.uint64)
     opp = np.where(tm == 1, sel[:, 1], sel[:, 0]).astype(np.uint64)
     out = {}
-    for mode in (gw, "0"):
-        monkeypatch.setenv("BZ_TTT_GW", mode)
+    for mode in (gw, -1):
         for ev, sims in (("hash", 120), ("uniform", 50)):
-            eng = _engine("ttt", len(sel), sims, ev)
+            eng = _engine("ttt", len(sel), sims, ev, ttt_lanes=mode)
             eng.set_roots(own, opp, tm)
             eng.reset_counters()
             eng.search()
@@ -979,15 +979,14 @@ def test_ttt_specialised_fused_search_equals_generic_kernel_and_oracle(gw, monke
             eng.status()
             out[(mode, ev)] = (N, W.view(np.uint32), P.view(np.uint32), eng.counters())
     for ev, sims in (("hash", 120), ("uniform", 50)):
-        a, b = out[(gw, ev)], out[("0", ev)]
+        a, b = out[(gw, ev)], out[(-1, ev)]
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
         assert a[3] == b[3], (a[3], b[3])
         for g in range(0, len(sel), 25):
             n, w, p, _ = orc.mcts_search(orc.GAME_TTT, int(own[g]), int(opp[g]), int(tm[g]), sims,
                                          orc.EVAL_HASH if ev == "hash" else orc.EVAL_UNIFORM)
             assert np.array_equal(a[0][g], n) and np.array_equal(a[1][g], w.view(np.uint32))
-    monkeypatch.setenv("BZ_TTT_GW", gw)
-    _check_selfplay("ttt", 96, 40, "hash", 4, 0, 7, base=300)
+    _check_selfplay("ttt", 96, 40, "hash", 4, 0, 7, base=300, ttt_lanes=gw)
 
 
 @pytest.mark.parametrize("C,NB", [(64, 3), (256, 2)])
@@ -1025,13 +1024,12 @@ def test_net_bf16_mfma_other_widths_vs_oracle_bf16_emulation(C, NB):
 
 
 # ---------------------------------------------------------------- opt-in search features
-@pytest.mark.parametrize("gw", ["2", "4", "0"])
-def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw, monkeypatch):
+@pytest.mark.parametrize("gw", [2, 4, -1])
+def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw):
     """Dirichlet noise on the root priors (float32 log / Gamma sampler spec'd to the bit): root
     N / W / P of noisy searches and complete noisy self-play games equal the oracle's, for the TTT-specialised
-    fused kernel (2, 4 lanes), the generic fused kernel (BZ_TTT_GW=0, and Reversi) and the step kernels (f32 net)."""
+    fused kernel (2, 4 lanes), the generic fused kernel (ttt_lanes = -1, and Reversi) and the step kernels (f32 net)."""
     from betazero_amd.net import DeviceNet
-    monkeypatch.setenv("BZ_TTT_GW", gw)
     d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
     live = d["pos"][d["pos"][:, 4] == 0]
     sel = live[np.random.default_rng(1).choice(len(live), 120, replace=False)]
@@ -1039,7 +1037,8 @@ def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw, monkeyp
     own = np.where(tm == 1, sel[:, 0], sel[:, 1]).astype(np.uint64)
     opp = np.where(tm == 1, sel[:, 1], sel[:, 0]).astype(np.uint64)
     for alpha in (0.3, 1.0):
-        eng = _engine("ttt", len(sel), 60, "hash", seed=5, game_id_base=1000, dirichlet_alpha=alpha, dirichlet_eps=0.25)
+        eng = _engine("ttt", len(sel), 60, "hash", seed=5, game_id_base=1000, dirichlet_alpha=alpha, dirichlet_eps=0.25,
+                      ttt_lanes=gw)
         eng.set_roots(own, opp, tm)
         eng.search()
         N, W, P = eng.root_stats()
@@ -1049,7 +1048,7 @@ def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw, monkeyp
                                          dir_alpha=alpha, dir_eps=0.25, seed=5, gid=1000 + g, ply=0)
             assert np.array_equal(N[g], n) and np.array_equal(W[g].view(np.uint32), w.view(np.uint32)), (alpha, g)
             assert np.array_equal(P[g].view(np.uint32), p.view(np.uint32)), (alpha, g)
-    if gw != "4":
+    if gw != 4:
         return
     # Reversi: generic fused kernel (hash) and the step kernels (f32 net), whole games with a fresh draw per move
     for ev, oev, net, onet, n_games, sims in (("hash", orc.EVAL_HASH, None, None, 24, 40),):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # In-kernel stamps (s_memtime per phase, in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz) of the
-# fused net kernel.  Builds the diagnostic variant into its OWN file (betazero_amd/libbz_hip.stamps.so);
+# fused net kernel.  Builds the diagnostic variant into its OWN file (build/variants/libbz_hip.stamps.so);
 # the product library is not touched.  FP8=1 for the fp8 kernel.  Run on the GPU box (gpurun).
 set -e
 cd "$(dirname "$0")/.."
