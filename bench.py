@@ -131,6 +131,10 @@ def rehearsal(args, rank, world):
     rows = sum(len(unpack_example_block(b)) for row in bd.split_gathered(gathered, sizes) for b in row)
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": None,
+                                   "device_name": "cpu (rehearsal)", "device_uuid": "", "games_finished": 0.0, "seconds": dt,
+                                   "pid": os.getpid()})
     if rank == 0:
         print(json.dumps({"metric": "selfplay_games_per_s", "value": None, "unit": "games/s", "n_gpus": dist.get_world_size(),
                           "steps": K, "warmup": args.warmup or 0, "ms_per_step": float(t[0]) / K * 1e3,
@@ -138,6 +142,7 @@ def rehearsal(args, rank, world):
                           "data": "synthetic", "rehearsal": True,
                           "config": {"workload": "CPU rehearsal of the multi-rank plumbing only (no GPU in this "
                                                  "process): launcher, process group, one all-gather, timing"},
+                          "ranks": {"backend": "gloo", "world_size": world, "distinct_devices": 0, "per_rank": ranks},
                           "collectives": len(calls), "block_bytes_per_rank": int(sum(sizes)),
                           "gathered_bytes": int(gathered.numel()), "pooled_rows": int(rows)}))
 
@@ -170,6 +175,18 @@ def usable_cores():
 
 
 # ------------------------------------------------------------------ CPU baselines (rank 0, N = 1)
+def _py_twin():
+    """oracle/py_twin.py as a module (loaded by path: `oracle` stays the package it is on sys.path)"""
+    import importlib.util
+    if "bz_py_twin" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("bz_py_twin", os.path.join(ROOT, "oracle", "py_twin.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["bz_py_twin"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["bz_py_twin"]
+
+
+
 def cpu_baseline_reversi(sims, budget_s=12.0):
     """(i) "port": the C oracle on ALL host cores, one game per thread, 2 searched moves each of cfg-3
     games with the bf16-emulating net, extrapolated at 58 searched moves per game.
@@ -199,10 +216,16 @@ def cpu_baseline_reversi(sims, budget_s=12.0):
     out = {"value": sum(done) / dt / PLIES_PER_GAME, "unit": "games/s", "cores": cores, "kind": "port",
            "sample": f"{cores} threads x {moves} searched moves ({sims} sims, {sims + 1} net evals per move) of "
                      f"cfg-3 games in {dt:.1f} s; extrapolated at {PLIES_PER_GAME} searched moves per game"}
+    # the same port on ONE thread (1 thread and all cores)
+    t0 = time.time()
+    r1 = orc.selfplay_game(orc.GAME_REVERSI, 0, sims, orc.EVAL_NET_BF16, 8, 1, 0, net=net, max_moves=1)
+    dt1 = time.time() - t0
+    out["one_thread"] = {"value": len(r1["own"]) / dt1 / PLIES_PER_GAME, "unit": "games/s", "cores": 1, "kind": "port",
+                         "sample": f"1 thread x 1 searched move ({sims} sims) of a cfg-3 game in {dt1:.1f} s; extrapolated at "
+                                   f"{PLIES_PER_GAME} searched moves per game"}
     # (ii) the Python loop, one core
     try:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import py_twin
+        py_twin = _py_twin()
         import betazero_amd as bz
         nthr = torch.get_num_threads()
         torch.set_num_threads(1)
@@ -231,6 +254,38 @@ def cpu_baseline_reversi(sims, budget_s=12.0):
     except Exception as e:  # the baseline must never take the bench line down
         out["python_loop"] = {"value": None, "error": repr(e)}
     return out
+
+
+def cfg1_python_loop(n_games=100, sims=25):
+    """BASELINE cfg 1 (plumbing, CPU): the build-authored Python MCTS (oracle/py_twin.py -- the reference has no MCTS,
+    SURVEY 0 F2) over betazero_amd's API-compatible TicTacToeBoard, 25 sims/move, uniform priors, seed 0, 100 games,
+    ONE core; every game must be legal and finish.  The trajectory loop has the semantics of the reference's
+    TicTacToeHeadless.play (src/tic_tac_toe/tic_tac_toe.py:13-34): position recorded before every move, winner from
+    is_game_over."""
+    py_twin = _py_twin()
+    import betazero_amd as bz
+    tw = py_twin.Twin("ttt", "uniform", boards=(bz.ReversiBoard, bz.TicTacToeBoard))
+    t0 = time.time()
+    plies, res, legal = 0, {1: 0, -1: 0, 0: 0}, True
+    for g in range(n_games):
+        ex, w, _ = tw.selfplay(g, sims, 0, 0, 0)
+        plies += len(ex)
+        res[w] += 1
+        # replay through the board API: every recorded action legal, the game really over, the winner as recorded
+        b, p = bz.TicTacToeBoard(), 1
+        for (_own, _opp, _pi, mover, a) in ex:
+            legal &= mover == p and bool(b.is_valid_move(a // 3, a % 3))
+            b = b.make_move(a // 3, a % 3, p)
+            p = -p
+        over, win = b.is_game_over()
+        legal &= bool(over) and (win or 0) == w
+    dt = time.time() - t0
+    return {"metric": "selfplay_games_per_s", "value": n_games / dt, "unit": "games/s", "cores": 1,
+            "config": {"workload": f"ttt3x3_{n_games}games_{sims}sims_python_loop_cpu",
+                       "loop": "build-authored Python MCTS (oracle/py_twin.py) over betazero_amd.TicTacToeBoard; "
+                               "the reference has no MCTS loop to time"},
+            "games": n_games, "plies_per_game": plies / n_games, "results_x_o_draw": [res[1], res[-1], res[0]],
+            "all_games_legal_and_finished": bool(legal), "seconds": dt}
 
 
 def cpu_baseline_ttt(sims):
@@ -353,13 +408,13 @@ def run_env(ctx, n, K, W):
                                  "(SQ_ACTIVE_INST_VALU, profiles/r02_pmc_env_sq_pmc.csv)"}}
 
 
-def run_ttt(ctx, B, sims, K, W):
+def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
     """BASELINE cfg 2: TTT, uniform priors, the whole search of a move is one fused tree kernel"""
     from betazero_amd import _lib
     from betazero_amd.engine import SelfPlayEngine
     L = _lib.lib()
     eng = SelfPlayEngine("ttt", B, sims, "uniform", game_id_base=ctx.rank * B, game_id_stride=ctx.world * B,
-                         device=ctx.dev)
+                         device=ctx.dev, ttt_lanes=ttt_lanes)
 
     def step():
         eng.reset_games()
@@ -391,7 +446,8 @@ def run_ttt(ctx, B, sims, K, W):
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic", "dtype": "u64+f32",
             "config": {"workload": f"ttt3x3_{B}games_{sims}sims_uniform_tree_only", "games_per_gpu": B,
-                       "sims_per_move": sims, "step": "one complete self-play iteration of all games"},
+                       "sims_per_move": sims, "step": "one complete self-play iteration of all games",
+                       "ttt_lanes": ttt_lanes if ttt_lanes else (2 if B >= 32768 else 4)},
             "roofline": {"bound": "hbm", "kernel": "k_search_fused<TicTacToe>", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tb / max(launches, 1)},
@@ -496,6 +552,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     if args.mode == "iteration":
         fin1, fin0 = K * B, 0
     games = float(fin1 - fin0)
+    own_games, own_dt = games, dt
     if ctx.world > 1:
         t = torch.tensor([dt, games], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -505,6 +562,15 @@ def run_reversi(ctx, args, B, sims, K, W):
     for e in engs:
         for k, v in e.counters().items():
             cnt[k] = cnt.get(k, 0) + v
+    ranks = None
+    if ctx.world > 1:  # untimed: which device every rank really held, what it finished and how long it took
+        pr = torch.cuda.get_device_properties(ctx.local)
+        mine = {"rank": ctx.rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": ctx.local,
+                "device_name": pr.name, "device_uuid": str(getattr(pr, "uuid", "")),
+                "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
+                "games_finished": own_games, "seconds": own_dt, "pid": os.getpid()}
+        ranks = [None] * ctx.world
+        dist.all_gather_object(ranks, mine)
     if ctx.rank != 0:
         return None
     out = {"metric": "selfplay_games_per_s", "value": games / dt, "unit": "games/s", "n_gpus": ctx.world, "steps": K,
@@ -568,6 +634,10 @@ def run_reversi(ctx, args, B, sims, K, W):
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": cnt["n_net_leaves"] * NET_FLOP_PER_POS / dt / 1e12,
                            "peak": peak, "unit": "TFLOP/s", "frac": cnt["n_net_leaves"] * NET_FLOP_PER_POS / dt / 1e12 / peak,
                            "traffic": None, "note": "--no-kernel-timers: whole-run flops / wall time (lower bound)"}
+    if ranks is not None:
+        out["ranks"] = {"backend": ctx.backend + (" (RCCL)" if ctx.backend == "nccl" else ""), "world_size": ctx.world,
+                        "distinct_devices": len({(r["device_uuid"] or r["pci_bus_id"], r["device_index"]) for r in ranks}),
+                        "per_rank": ranks}
     out["sims_per_s"] = cnt["n_sims"] * ctx.world / dt
     out["net_evals_per_s"] = cnt["n_net_leaves"] * ctx.world / dt
     out["net_tflops_e2e"] = cnt["n_net_leaves"] * ctx.world * NET_FLOP_PER_POS / dt / 1e12
@@ -600,6 +670,8 @@ def main():
                     help="N > 1: weak = --games per GPU (default, the headline); strong = --games in total, split over the ranks")
     ap.add_argument("--reuse-subtree", action="store_true", help="supplementary: keep the chosen child's subtree (DESIGN 3.10)")
     ap.add_argument("--dirichlet-eps", type=float, default=0.0, help="supplementary: root noise weight (alpha 0.5; DESIGN 3.9)")
+    ap.add_argument("--ttt-lanes", type=int, default=0, choices=[-1, 0, 1, 2, 4, 8],
+                    help="--workload ttt: lanes per game of the fused search (bz_engine_cfg.ttt_lanes; 0 = default, -1 = generic kernel)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ:
@@ -626,8 +698,13 @@ def main():
         rehearsal(args, ctx.rank, ctx.world)
         dist.destroy_process_group()
         return
-    local = local % n_dev
+    if local >= n_dev:
+        if ctx.backend == "nccl":
+            sys.exit(f"bench.py: --gpus {ctx.world} but only {n_dev} GPU(s) visible: RCCL needs one device per rank "
+                     f"(BZ_DIST_BACKEND=gloo rehearses the multi-rank path with ranks sharing a card)")
+        local = local % n_dev  # gloo rehearsal: the ranks share the visible card(s) and say so in the line
     ctx.dev = f"cuda:{local}"
+    ctx.local = local
     torch.cuda.set_device(local)
     if ctx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -656,7 +733,7 @@ def main():
     elif args.workload == "ttt":
         sims = args.sims or 50
         out = run_ttt(ctx, args.games or 65536, sims, args.steps if args.steps is not None else 20,
-                      args.warmup if args.warmup is not None else 2)
+                      args.warmup if args.warmup is not None else 2, args.ttt_lanes)
         if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_ttt(sims)
     else:
@@ -672,14 +749,23 @@ def main():
         if ctx.rank == 0 and ctx.world == 1:
             if not args.no_secondary:  # cfg 2 and cfg 5 in the same driver-timed process (a few seconds)
                 sec = {}
+                a_fp8 = argparse.Namespace(**{**vars(args), "precision": "fp8", "mode": "steady"})
+                a_iter = argparse.Namespace(**{**vars(args), "mode": "iteration"})
                 for name, fn in (("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
                                  ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
-                                 ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3))):
+                                 ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3)),
+                                 # cfg 5 as SURVEY 7 reads it: the fp8 net as the in-loop evaluator of 8192 concurrent games
+                                 ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 3, 1)),
+                                 # the steady-state figure's cross-check: ONE complete iteration, every game from its
+                                 # opening to the last finished game, under the same clock
+                                 ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0)),
+                                 ("cfg1", cfg1_python_loop)):
                     try:
                         note(f"secondary {name}")
                         r = fn()
                         sec[name] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config",
-                                                       "roofline")}
+                                                       "roofline", "cores", "games", "plies_per_game", "results_x_o_draw",
+                                                       "all_games_legal_and_finished", "seconds") if k in r}
                     except Exception as e:
                         sec[name] = {"error": repr(e)}
                 out["secondary"] = sec

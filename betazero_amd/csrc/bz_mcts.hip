@@ -88,10 +88,12 @@ struct Cnt { u32 v[CNT_N]; };
 // Diagnostic build only (betazero_amd.build.build_variant("treestamps", ["-DBZ_EXP_TREE_STAMPS"]), tools/exp_tree_stamps.py):
 // shader-clock stamps between the phases of k_tree_step, summed over all waves into counters[8..15].  The product build
 // compiles the empty struct away.
-#ifdef BZ_EXP_TREE_STAMPS
+#if defined(BZ_EXP_TREE_STAMPS) || defined(BZ_EXP_NO_COOP_ENV)
 #ifndef BZ_EXPERIMENT
-#error "BZ_EXP_TREE_STAMPS is a diagnostic option: build it through betazero_amd.build.build_variant()"
+#error "BZ_EXP_* are diagnostic options: build them through betazero_amd.build.build_variant()"
 #endif
+#endif
+#ifdef BZ_EXP_TREE_STAMPS
 struct Stamps {
     u64 last; u32 acc[8];
     __device__ __forceinline__ void start() { for (int k = 0; k < 8; ++k) acc[k] = 0; last = __builtin_readcyclecounter(); }
@@ -212,10 +214,11 @@ struct PathHbm {  // lane d of the group keeps entry d in registers during the w
     }
     __device__ __forceinline__ void flush(int sub, int depth) const { if (sub < depth && sub < kGW) p[sub] = mine; }
 };
+struct PathEntLds { u32 eidx; u32 w0; float W; };  // 12 bytes: LDS capacity decides how many games a CU holds
 struct PathLds {
-    PathEnt* p;  // this game's MAXD entries
+    PathEntLds* p;  // this game's MAXD entries
     __device__ __forceinline__ void put(int d, int sub, u32 eidx, u32 w0, float W) const {
-        if (sub == 0) { PathEnt e; e.eidx = eidx; e.w0 = w0; e.W = W; e.pad = 0; p[d] = e; }
+        if (sub == 0) { PathEntLds e; e.eidx = eidx; e.w0 = w0; e.W = W; p[d] = e; }
     }
 };
 
@@ -236,8 +239,63 @@ struct LogitSrc {
 // ascending action order by a serial shuffle scan so that the result is bit-identical to the
 // sequential spec; the backup updates one path edge per lane.
 
+// ---- the env step of child creation, shared out over a lane group.  All kGW lanes of a group would otherwise
+// compute the same 8 rays of make_move (reversi_board.py:49-58) and the same 8 rays of the child's legal mask
+// (:25-41, :87-88) redundantly -- ~400 integer instructions per wave, on the walk's critical path.  Instead lane
+// (sub & 7) takes ONE ray direction: directions 0..3 shift left by 1 / 8 / 7 / 9; 4..7 are their opposites,
+// computed as the same left shifts on the bit-reversed boards (bit i <-> 63 - i maps a right shift onto a left
+// shift; the column-wrap mask is symmetric), and the 8 partial masks are OR-ed across the lanes with DPP moves.
+__device__ __forceinline__ u64 brev64(u64 x) { return ((u64)__brev((u32)x) << 32) | (u64)__brev((u32)(x >> 32)); }
+__device__ __forceinline__ u64 or8(u64 x) {  // OR over the 8 lanes of a half row (lanes 8..15 of a 16-lane group mirror 0..7)
+    u32 lo = (u32)x, hi = (u32)(x >> 32);
+    lo |= xchg<1>(lo); hi |= xchg<1>(hi);
+    lo |= xchg<2>(lo); hi |= xchg<2>(hi);
+    lo |= xchg<4>(lo); hi |= xchg<4>(hi);
+    return ((u64)hi << 32) | lo;
+}
+// one ray direction (left shift by s) of generate_possible_moves / of the flips of placing on m; o = opponent
+// stones pre-masked against column wrap; runs of <= 6 stones by parallel prefix (2 + 2 + 2 cells)
+__device__ __forceinline__ u64 ray_fill(u64 seed, u64 o, int s) {
+    u64 fl = o & (seed << s);
+    fl |= o & (fl << s);
+    const u64 pl = o & (o << s);
+    fl |= pl & (fl << (2 * s));
+    fl |= pl & (fl << (2 * s));
+    return fl;
+}
+template <class G, bool kShare = (G::kGame != 0 && G::GW >= 8)>
+struct CoopChild {  // tic-tac-toe / narrow groups: nothing to share out
+    static __device__ __forceinline__ void run(u64 own, u64 opp, int act, int, u64* cown, u64* copp, u64* legal) {
+        G::apply(own, opp, act, cown, copp);
+        *legal = G::legal(*cown, *copp);
+    }
+};
+template <class G>
+struct CoopChild<G, true> {
+    static __device__ __forceinline__ void run(u64 own, u64 opp, int act, int sub, u64* cown, u64* copp, u64* legal) {
+        const int d = sub & 7, k = d & 3;
+        const int s = k == 0 ? 1 : (k == 1 ? 8 : (k == 2 ? 7 : 9));
+        const bool rv = d >= 4;
+        const u64 wrap = k == 1 ? ~0ULL : kInner;
+        u64 co = opp, cp = own;
+        if (act != kPass) {
+            const u64 m = 1ULL << act;
+            const u64 a = rv ? brev64(own) : own, b = rv ? brev64(opp) : opp, mm = rv ? brev64(m) : m;
+            u64 fl = ray_fill(mm, b & wrap, s);
+            fl = ((fl << s) & a) ? fl : 0ULL;
+            const u64 f = or8(rv ? brev64(fl) : fl);
+            co = opp & ~f; cp = own | m | f;
+        }
+        const u64 a = rv ? brev64(co) : co, b = rv ? brev64(cp) : cp;
+        const u64 mv = ray_fill(a, b & wrap, s) << s;
+        *legal = or8(rv ? brev64(mv) : mv) & ~(co | cp) & G::kValid;
+        *cown = co; *copp = cp;
+    }
+};
+
 // what the walk starts from: the root's position, mover colour and child count (its edges start at index 0)
-struct RootRef { u64 own, opp; int tm; int n; u32 sumN; };
+// `pre`: this lane's root edge (index sub) when the caller fetched the first kGW root edges ahead of the walk
+struct RootRef { u64 own, opp; int tm; int n; u32 sumN; bool has_pre; Edge pre; };
 // the node select created (valid when a child was created)
 struct LeafPos { u64 own, opp, legal; u32 info; };
 
@@ -263,7 +321,8 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, c
         for (int base = 0; base < n; base += kGW) {
             Cand cd; cd.i = base + sub; cd.sc = -__builtin_inff(); cd.W = 0.0f; cd.w0 = 0; cd.w3 = 0;
             if (cd.i < n) {
-                Edge e = ed[cd.i];
+                Edge e = root.pre;
+                if (!(root.has_pre && depth == 0 && base == 0)) e = ed[cd.i];
                 const u32 N = e_N(e.w0);
                 float q = N > 0 ? fdiv(e.W, (float)N) : 0.0f;
                 float u = E.c_puct * e.P;
@@ -292,11 +351,15 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, c
         }
         st.mark(3);
         const int act = e_action(bestw0);
-        u64 cown, copp;
+        u64 cown, copp, lg;
+#ifdef BZ_EXP_NO_COOP_ENV
         G::apply(pown, popp, act, &cown, &copp);
+        lg = G::legal(cown, copp);
+#else
+        CoopChild<G>::run(pown, popp, act, sub, &cown, &copp, &lg);
+#endif
         const u32 id = n_nodes_g++;
         const int tm = (depth & 1) ? root.tm : -root.tm;  // child's mover: the colours alternate down the walk (passes included)
-        u64 lg = G::legal(cown, copp);
         int tv = 0;
         const bool term = G::terminal(cown, copp, tm, lg, &tv);
         lp.own = cown; lp.opp = copp; lp.legal = term ? 0 : lg;
@@ -409,22 +472,25 @@ __device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u3
 // in between), so the backup is one 8-byte store per path edge and reads nothing but the path.  The
 // deepest edge leads to the leaf: when the leaf was expanded just now (exp_n > 0 edges from exp_e0),
 // its edge count / first edge go into that edge's words with the same stores.
-__device__ __forceinline__ void backup_edge(Edge* edges, const PathEnt& pe, float val, bool deepest, u32 leaf, u32 exp_e0, int exp_n) {
+template <class PE>
+__device__ __forceinline__ uint2 backup_edge(Edge* edges, const PE& pe, float val, bool deepest, u32 leaf, u32 exp_e0, int exp_n) {
     u32 w0 = pe.w0 + 1u;
     if (deepest && exp_n > 0) {
         w0 |= (u32)exp_n << kNchShift;
         edges[pe.eidx].w3 = leaf | (exp_e0 << kChildBits);
     }
-    *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(w0, __float_as_uint(pe.W + val));
+    const uint2 wr = make_uint2(w0, __float_as_uint(pe.W + val));
+    *reinterpret_cast<uint2*>(edges + pe.eidx) = wr;
+    return wr;
 }
 
-template <int kGW>
-__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, const PathEnt* path,
+template <int kGW, class PE>
+__device__ __forceinline__ void dev_backup(const EngineDev& E, int g, int sub, int depth, float v, const PE* path,
                                            u32 leaf, u32 exp_e0, int exp_n, Cnt& c) {
     Edge* edges = E.edges + (size_t)g * E.ecap;
     const int dmax = depth < E.maxd ? depth : E.maxd;
     for (int d = sub; d < dmax; d += kGW) {
-        const PathEnt pe = path[d];
+        const PE pe = path[d];
         const float val = ((dmax - 1 - d) & 1) ? v : -v;  // deepest edge gets -v
         backup_edge(edges, pe, val, d == depth - 1, leaf, exp_e0, exp_n);
     }
@@ -640,6 +706,13 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
         u32 root_base = 0;
         if (E.reuse) root_base = E.g_root_base[g];
         PathEnt pe0 = path[sub];  // (maxd >= kGW for every game)
+        // the walk's first load too: root edges 0..kGW-1 (the root's edges start at index 0; whatever this step's
+        // backup / expansion changes in them is patched in registers below) -- their latency hides behind the
+        // evaluator row's round trip and the softmax instead of heading the walk
+        Edge* const edges_g = E.edges + (size_t)g * E.ecap;
+        Edge re0 = edges_g[sub];
+        pin(re0.w0); pin(re0.W); pin(re0.P); pin(re0.w3);
+        bool pre_ok = true;
         pin(kind); pin(state); pin(leaf); pin(ninfo); pin(ne); pin(nn); pin(row); pin(depth0); pin(root_n); pin(rtm);
         pin(nlegal); pin(rown); pin(ropp); pin(root_base); pin(pe0.eidx); pin(pe0.w0); pin(pe0.W);
         const bool active = state == 0 && kind != LEAF_NONE;
@@ -652,17 +725,25 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 v = E.value[row];
                 n = dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c, st);
                 if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.root_n[g] = (u32)n; }
-                if (leaf == 0) root_n = n;
+                if (leaf == 0) { root_n = n; pre_ok = false; }  // the root's edges did not exist when re0 was fetched
             } else {
                 v = (float)((int)((ninfo >> 9) & 3u) - 1);
             }
             // backup: path entries 0..kGW-1 are in registers already; deeper walks (rare) load theirs
-            Edge* edges = E.edges + (size_t)g * E.ecap;
+            Edge* edges = edges_g;
             const int dmax = depth0 < E.maxd ? depth0 : E.maxd;
-            if (sub < dmax) backup_edge(edges, pe0, ((dmax - 1 - sub) & 1) ? v : -v, sub == depth0 - 1, leaf, e0, n);
+            uint2 wr = make_uint2(0u, 0u);
+            if (sub < dmax) wr = backup_edge(edges, pe0, ((dmax - 1 - sub) & 1) ? v : -v, sub == depth0 - 1, leaf, e0, n);
             for (int d = sub + kGW; d < dmax; d += kGW)
                 backup_edge(edges, path[d], ((dmax - 1 - d) & 1) ? v : -v, d == depth0 - 1, leaf, e0, n);
             if (sub == 0) c.v[CNT_EDGES_BACKED] += (u32)dmax;
+            if (dmax >= 1) {  // the path's root edge (lane 0 wrote it): the same words into the lane that holds it in re0
+                const u32 pe_e = (u32)__shfl((int)pe0.eidx, 0, kGW), w0n = (u32)__shfl((int)wr.x, 0, kGW), Wn = (u32)__shfl((int)wr.y, 0, kGW);
+                if ((u32)sub == pe_e) {
+                    re0.w0 = w0n; re0.W = __uint_as_float(Wn);
+                    if (depth0 == 1 && n > 0) re0.w3 = leaf | (e0 << kChildBits);
+                }
+            }
         }
         st.mark(2);
         if (do_select) {
@@ -672,7 +753,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 u32 leaf2; int k2, depth; float tv;
                 LeafPos lpos; lpos.own = 0; lpos.opp = 0; lpos.legal = 0; lpos.info = 0;
                 RootRef root; root.own = rown; root.opp = ropp; root.tm = rtm; root.n = root_n;
-                root.sumN = sim_idx + root_base;
+                root.sumN = sim_idx + root_base; root.has_pre = pre_ok; root.pre = re0;
                 PathHbm<kGW> sink; sink.p = path; sink.mine.eidx = 0; sink.mine.w0 = 0; sink.mine.W = 0.0f; sink.mine.pad = 0;
                 dev_select<G>(E, g, sub, root, nn, leaf2, k2, depth, tv, c, sink, lpos, st);  // ---- one round trip per level
                 sink.flush(sub, depth);
@@ -718,10 +799,10 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
 template <class G>
 __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind) {
     constexpr int kGW = G::GW, kGPB = 256 / kGW;
-    __shared__ PathEnt s_path[kGPB][G::MAXD];
+    __shared__ PathEntLds s_path[kGPB][G::MAXD];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
-    PathEnt* mypath = s_path[threadIdx.x / kGW];
+    PathEntLds* mypath = s_path[threadIdx.x / kGW];
     Cnt c = {};
     if (g < E.B && E.g_state[g] == 0) {
         bool ok = true;
@@ -731,6 +812,7 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
             u32 nn = 1, ne = 0;
             LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
             RootRef root; root.own = E.g_own[g]; root.opp = E.g_opp[g]; root.tm = E.g_to_move[g];
+            root.has_pre = false; root.pre.w0 = 0; root.pre.W = 0.0f; root.pre.P = 0.0f; root.pre.w3 = 0;
             ls.h = hash_pos(root.own, root.opp);
             group_fence();
             Stamps st; st.start();
@@ -788,10 +870,10 @@ template <int kGW>
 __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_kind) {
     using G = TicTacToe;
     constexpr int kGPB = 256 / kGW, kCH = (G::MAXCH + kGW - 1) / kGW;
-    __shared__ PathEnt s_path[kGPB][G::MAXD];
+    __shared__ PathEntLds s_path[kGPB][G::MAXD];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
-    PathEnt* mypath = s_path[threadIdx.x / kGW];
+    PathEntLds* mypath = s_path[threadIdx.x / kGW];
     Cnt c = {};
     if (g < E.B && E.g_state[g] == 0) {
         bool ok = true;
@@ -873,7 +955,7 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                         pe_idx = e0 + (u32)best;
                         if (lead) {
                             c.v[CNT_CHILD_SCORED] += (u32)n;
-                            if (depth < E.maxd) { PathEnt pe; pe.eidx = pe_idx; pe.w0 = bestN; pe.W = bestW; pe.pad = 0; mypath[depth] = pe; }
+                            if (depth < E.maxd) { PathEntLds pe; pe.eidx = pe_idx; pe.w0 = bestN; pe.W = bestW; mypath[depth] = pe; }
                             else atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
                         }
                         depth++;
@@ -915,7 +997,7 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                 group_fence();  // the lead lane's LDS path entries -> the lanes that back them up
                 for (int d = sub; d < dmax; d += kGW) {
                     if (d == 0) continue;
-                    PathEnt pe = mypath[d];
+                    PathEntLds pe = mypath[d];
                     float val = ((dmax - 1 - d) & 1) ? v : -v;
                     *reinterpret_cast<uint2*>(edges + pe.eidx) = make_uint2(pe.w0 + 1u, __float_as_uint(pe.W + val));
                 }

@@ -108,6 +108,11 @@ def test_bench_gpus2_starts_its_own_ranks_cpu_rehearsal():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["collectives"] == 1
     assert out["gathered_bytes"] == 2 * out["block_bytes_per_rank"] and out["pooled_rows"] > 0
+    # the line proves its own ranks: backend, one entry per rank with the device it held, what it finished and its own clock
+    rk = out["ranks"]
+    assert rk["backend"] == "gloo" and rk["world_size"] == 2 and [r["rank"] for r in rk["per_rank"]] == [0, 1]
+    assert len({r["pid"] for r in rk["per_rank"]}) == 2
+    assert all(set(("local_rank", "device_index", "device_uuid", "games_finished", "seconds")) <= set(r) for r in rk["per_rank"])
 
 
 def test_bench_refuses_gpu_count_mismatch():

@@ -27,14 +27,13 @@ if has pmc_tower; then
   run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tower_tcc" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_tcc.txt" 2>&1
 fi
 if has pmc_ttt; then
-  for gw in 2 0; do   # 2 = the TTT-specialised fused search, 0 = the generic fused kernel (the "before")
-    export BZ_TTT_GW=$gw
-    run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d "$OUT/pmc_ttt_sq_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_sq_gw$gw.json" 2> "$OUT/pmc_ttt_sq_gw$gw.err"
-    run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_ttt_tcc_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_tcc_gw$gw.json" 2> "$OUT/pmc_ttt_tcc_gw$gw.err"
-    run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_ttt_fetch_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_fetch_gw$gw.json" 2> "$OUT/pmc_ttt_fetch_gw$gw.err"
-    run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_ttt_write_gw$gw" -o t -- python3 bench.py --workload ttt --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_write_gw$gw.json" 2> "$OUT/pmc_ttt_write_gw$gw.err"
+  for gw in 2 0; do   # 2 = the TTT-specialised fused search, 0 = the generic fused kernel (the "before": --ttt-lanes -1)
+    if [ $gw = 0 ]; then LANES="--ttt-lanes -1"; else LANES="--ttt-lanes $gw"; fi
+    run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d "$OUT/pmc_ttt_sq_gw$gw" -o t -- python3 bench.py --workload ttt $LANES --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_sq_gw$gw.json" 2> "$OUT/pmc_ttt_sq_gw$gw.err"
+    run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_ttt_tcc_gw$gw" -o t -- python3 bench.py --workload ttt $LANES --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_tcc_gw$gw.json" 2> "$OUT/pmc_ttt_tcc_gw$gw.err"
+    run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_ttt_fetch_gw$gw" -o t -- python3 bench.py --workload ttt $LANES --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_fetch_gw$gw.json" 2> "$OUT/pmc_ttt_fetch_gw$gw.err"
+    run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_ttt_write_gw$gw" -o t -- python3 bench.py --workload ttt $LANES --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_write_gw$gw.json" 2> "$OUT/pmc_ttt_write_gw$gw.err"
   done
-  unset BZ_TTT_GW
 fi
 if has pmc_env; then
   run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/pmc_env_sq" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_sq.txt" 2>&1
