@@ -1,31 +1,49 @@
 """8-fold symmetry augmentation + dedupe of (s, pi, z) examples on the GPU.
 Reference: TicTacToeDataset.expand_with_transforms, src/tic_tac_toe/SL/train.py:24-52
 (the 8 transforms in its order, then keep the first occurrence of every distinct
-(state, action) pair in insertion order)."""
-import numpy as np
+(state, action) pair in insertion order).
+
+Device in, device out: DeviceExamples (what gather_examples_device / SelfPlayEngine.device_examples hand over)
+stay on the GPU through the transforms, the dedupe and into train_step; host Examples are accepted too and come
+back as host Examples."""
 import torch
 
 from . import _lib
-from .engine import Examples
+from .engine import DeviceExamples, Examples
+
+
+def _first_occurrences(key8, own8, opp8, pi8):
+    """indices (ascending = insertion order) of the rows to keep: the first of every run of EXACTLY equal
+    (own, opp, pi) rows (SL/train.py:45-50 keeps the first of every exactly-equal pair).  Rows are grouped by the
+    kernel's 64-bit content key (stable sort: insertion order inside a group), then every row is compared WITH THE
+    HEAD OF ITS GROUP on the full content: equal -> a duplicate, dropped; different -> two contents sharing a key, kept.
+    A key collision can therefore never drop a distinct row."""
+    sk, order = torch.sort(key8, stable=True)
+    newrun = torch.ones_like(sk, dtype=torch.bool)
+    newrun[1:] = sk[1:] != sk[:-1]
+    heads = newrun.nonzero(as_tuple=True)[0]                 # sorted positions of the group heads
+    head_row = order[heads[torch.cumsum(newrun, 0) - 1]]     # for every sorted position: the row id of its group's head
+    same = (own8[order] == own8[head_row]) & (opp8[order] == opp8[head_row]) & (pi8[order] == pi8[head_row]).all(1)
+    return torch.sort(order[~(same & ~newrun)]).values
 
 
 def augment_examples(ex, dedupe=True, device="cuda:0"):
-    """Examples (n rows) -> Examples (<= 8n rows, row 8*i+t = transform t of row i before dedupe).
+    """Examples / DeviceExamples (n rows) -> the same type (<= 8n rows, row 8*i+t = transform t of row i before dedupe).
     z, mover and game carry over; `act` is permuted with the board; `ply` is kept."""
     _lib.require_gpu()
+    host_in = isinstance(ex, Examples)
+    if host_in:
+        ex = DeviceExamples.from_host(ex, device)
+    dev = ex.own.device
     n, na, size = len(ex), ex.pi.shape[1], ex.size
-    dev = torch.device(device)
-    own = torch.as_tensor(ex.own.view(np.int64)).to(dev)
-    opp = torch.as_tensor(ex.opp.view(np.int64)).to(dev)
-    onehot_cols = size * size
-    pi = torch.as_tensor(np.ascontiguousarray(ex.pi, dtype=np.float32)).to(dev)
+    own, opp, pi = ex.own.contiguous(), ex.opp.contiguous(), ex.pi.contiguous()
     own8 = torch.empty(8 * n, dtype=torch.int64, device=dev)
     opp8 = torch.empty(8 * n, dtype=torch.int64, device=dev)
     pi8 = torch.empty((8 * n, na), dtype=torch.float32, device=dev)
     key8 = torch.empty(8 * n, dtype=torch.int64, device=dev)
     # the move played, as a one-hot "policy", goes through the same kernel to permute `act`
     act1 = torch.zeros((n, na), dtype=torch.float32, device=dev)
-    act1[torch.arange(n, device=dev), torch.as_tensor(ex.act.astype(np.int64)).to(dev)] = 1.0
+    act1[torch.arange(n, device=dev), ex.act.to(torch.int64)] = 1.0
     act8 = torch.empty((8 * n, na), dtype=torch.float32, device=dev)
     scr_a = torch.empty(8 * n, dtype=torch.int64, device=dev)  # two distinct buffers: the kernel's outputs
     scr_b = torch.empty(8 * n, dtype=torch.int64, device=dev)  # are __restrict__
@@ -36,14 +54,8 @@ def augment_examples(ex, dedupe=True, device="cuda:0"):
                                          opp8.data_ptr(), pi8.data_ptr(), key8.data_ptr(), st))
         _lib.check(L.bz_augment_d4_batch(own.data_ptr(), opp.data_ptr(), act1.data_ptr(), n, size, na,
                                          scr_a.data_ptr(), scr_b.data_ptr(), act8.data_ptr(), None, st))
-    keep = torch.arange(8 * n, device=dev)
-    if dedupe:  # first occurrence of every distinct row, insertion order preserved
-        sk, order = torch.sort(key8, stable=True)
-        first = torch.ones_like(sk, dtype=torch.bool)
-        first[1:] = sk[1:] != sk[:-1]
-        keep = torch.sort(order[first]).values
-    src = (keep // 8).cpu().numpy()
-    k = keep
-    return Examples(own=own8[k].cpu().numpy().view(np.uint64), opp=opp8[k].cpu().numpy().view(np.uint64),
-                    pi=pi8[k].cpu().numpy(), z=ex.z[src], mover=ex.mover[src],
-                    act=act8[k].argmax(1).cpu().numpy().astype(np.uint8), game=ex.game[src], ply=ex.ply[src], size=size)
+    keep = _first_occurrences(key8, own8, opp8, pi8) if dedupe else torch.arange(8 * n, device=dev)
+    src = keep // 8
+    out = DeviceExamples(own=own8[keep], opp=opp8[keep], pi=pi8[keep], z=ex.z[src], mover=ex.mover[src],
+                         act=act8[keep].argmax(1).to(torch.uint8), game=ex.game[src], ply=ex.ply[src], size=size)
+    return out.cpu() if host_in else out

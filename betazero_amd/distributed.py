@@ -10,7 +10,7 @@ row counts, so neither a second collective for metadata nor an all-gather-v is n
 import torch
 import torch.distributed as dist
 
-from .engine import concat_examples, unpack_example_block
+from .engine import concat_device_examples, concat_examples, unpack_example_block, unpack_example_block_device
 
 
 def all_gather_example_blocks(blocks, group=None):
@@ -46,3 +46,15 @@ def gather_examples(engines, group=None):
         engines = [engines]
     gathered, sizes = all_gather_example_blocks([e.example_block() for e in engines], group)
     return concat_examples([unpack_example_block(b) for row in split_gathered(gathered, sizes) for b in row])
+
+
+def gather_examples_device(engines, group=None):
+    """gather_examples() without the host: the pooled rows of every rank's finished games as DeviceExamples on this
+    rank's GPU (one collective; backend "nccl" = RCCL over xGMI).  Every rank's engines are built alike (same game,
+    slot count, rounds), so a peer's block has the geometry of the local engine at the same position."""
+    if not isinstance(engines, (list, tuple)):
+        engines = [engines]
+    gathered, sizes = all_gather_example_blocks([e.example_block() for e in engines], group)
+    geoms = [e.block_geometry() for e in engines]
+    return concat_device_examples([unpack_example_block_device(b, g) for row in split_gathered(gathered, sizes)
+                                   for b, g in zip(row, geoms)])

@@ -52,6 +52,53 @@ class Examples:
         return a - b
 
 
+@dataclass
+class DeviceExamples:
+    """The same rows as Examples, as torch tensors living on the GPU: what the device-resident pipeline
+    gather -> augment -> train passes along (SL/train.py:24-52 then :85-136 in the reference's pipeline).
+    own/opp: int64 tensors holding the uint64 bit patterns."""
+    own: torch.Tensor
+    opp: torch.Tensor
+    pi: torch.Tensor
+    z: torch.Tensor
+    mover: torch.Tensor
+    act: torch.Tensor
+    game: torch.Tensor
+    ply: torch.Tensor
+    size: int
+
+    def __len__(self):
+        return int(self.own.shape[0])
+
+    def cpu(self):
+        """-> Examples (numpy, host)"""
+        n = lambda t: t.cpu().numpy()  # noqa: E731
+        return Examples(own=n(self.own).view(np.uint64), opp=n(self.opp).view(np.uint64), pi=n(self.pi), z=n(self.z),
+                        mover=n(self.mover), act=n(self.act), game=n(self.game), ply=n(self.ply).astype(np.int32), size=self.size)
+
+    @staticmethod
+    def from_host(ex, device="cuda:0"):
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        return DeviceExamples(own=t(ex.own.view(np.int64)), opp=t(ex.opp.view(np.int64)), pi=t(ex.pi.astype(np.float32)),
+                              z=t(ex.z.astype(np.int8)), mover=t(ex.mover.astype(np.int8)), act=t(ex.act.astype(np.uint8)),
+                              game=t(np.asarray(ex.game, np.int64)), ply=t(np.asarray(ex.ply, np.int32)), size=ex.size)
+
+    def states(self):
+        """canonical boards [n, size, size] int8 on the device: +1 = side to move, -1 = opponent"""
+        s = self.size
+        stride = 3 if s == 3 else 8
+        sh = torch.tensor([[stride * r + c for c in range(s)] for r in range(s)], dtype=torch.int64, device=self.own.device)
+        a = ((self.own[:, None, None] >> sh) & 1).to(torch.int8)
+        b = ((self.opp[:, None, None] >> sh) & 1).to(torch.int8)
+        return a - b
+
+
+def concat_device_examples(parts):
+    cat = lambda f: torch.cat([getattr(p, f) for p in parts])  # noqa: E731
+    return DeviceExamples(cat("own"), cat("opp"), cat("pi"), cat("z"), cat("mover"), cat("act"), cat("game"), cat("ply"),
+                          parts[0].size)
+
+
 class SelfPlayEngine:
     def __init__(self, game, n_games, sims, evaluator="uniform", net=None, c_puct=1.5, temp_moves=0, openings=0,
                  seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0", stagger=0,
@@ -206,6 +253,19 @@ class SelfPlayEngine:
         """finished games' rows, compacted on the device; only the valid rows cross PCIe"""
         return unpack_example_block(self.example_block())
 
+    def block_geometry(self):
+        """host-side description of this engine's example block (what its 256-byte header says), so that a block of the
+        same geometry -- this engine's, or a peer rank's copy of it after the all-gather -- can be unpacked on the
+        device without reading the header back"""
+        L = self.lay
+        offs = [o - L.ex_begin for o in (L.ex_own, L.ex_opp, L.ex_pi, L.ex_z, L.ex_mover, L.ex_act, L.ex_len, L.ex_winner)]
+        return {"B": self.B, "rounds": self.rounds, "t_max": self.t_max, "na": self.na, "game": self.game,
+                "size": self.size, "offs": offs, "ex_bytes": int(L.ex_bytes)}
+
+    def device_examples(self):
+        """finished games' rows as DeviceExamples: nothing leaves the GPU"""
+        return unpack_example_block_device(self.example_block(), self.block_geometry())
+
     def winners(self):
         t = self.example_tensors()
         return t["winner"].cpu().numpy(), t["len"].cpu().numpy()
@@ -286,6 +346,27 @@ def unpack_example_block(block):
     return Examples(own=pick(t["own"]).view(np.uint64), opp=pick(t["opp"]).view(np.uint64), pi=pick(t["pi"]),
                     z=pick(t["z"]), mover=pick(t["mover"]), act=pick(t["act"]), game=gid,
                     ply=k.cpu().numpy().astype(np.int32), size=m["size"])
+
+
+def unpack_example_block_device(block, geom):
+    """device example block -> DeviceExamples of the finished games, entirely on the device: the array views come from
+    `geom` (SelfPlayEngine.block_geometry() of an engine with the same configuration -- every rank's engines are built
+    alike), the game-id base / stride are read from the block's own header AS DEVICE SCALARS, the row selection is a
+    device-side nonzero().  No byte of the block visits the host."""
+    R, B, T, na = geom["rounds"], geom["B"], geom["t_max"], geom["na"]
+    assert block.numel() == geom["ex_bytes"], "example block of another geometry"
+    shapes = {"own": (R, B, T), "opp": (R, B, T), "pi": (R, B, T, na), "z": (R, B, T), "mover": (R, B, T),
+              "act": (R, B, T), "len": (R, B), "winner": (R, B)}
+    t = {}
+    for (name, dt, esz), off in zip(_EX_FIELDS, geom["offs"]):
+        n = int(np.prod(shapes[name])) * esz
+        t[name] = block[off:off + n].view(dt).view(*shapes[name])
+    meta = block[-256:].view(torch.int64)  # header words: [1] = game-id base, [2] = stride (device scalars)
+    valid = torch.arange(T, device=block.device)[None, None, :] < t["len"][:, :, None]
+    r, b, k = valid.nonzero(as_tuple=True)
+    pick = lambda a: a[r, b, k]  # noqa: E731
+    return DeviceExamples(own=pick(t["own"]), opp=pick(t["opp"]), pi=pick(t["pi"]), z=pick(t["z"]), mover=pick(t["mover"]),
+                          act=pick(t["act"]), game=meta[1] + r * meta[2] + b, ply=k.to(torch.int32), size=geom["size"])
 
 
 def concat_examples(parts):

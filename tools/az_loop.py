@@ -2,8 +2,9 @@
 """The closed AlphaZero loop on one GPU, end to end through the package's public pieces:
 
     self-play (SelfPlayEngine, bf16 MFMA net in the loop, Dirichlet root noise, temperature moves)
-      -> example block -> 8-fold D4 augmentation + dedupe on the device (augment_examples)
-      -> policy cross-entropy + value MSE steps with stock PyTorch autograd (train_step)
+      -> example block -> 8-fold D4 augmentation + exact dedupe on the device (augment_examples)
+      -> policy cross-entropy + value MSE steps with stock PyTorch autograd under bf16 autocast (train_step)
+         -- the rows never leave the GPU between the engine's example block and the optimiser step
       -> weights pushed back into the engine's net (refresh_device_net)
       -> batched arena against the reference's depth-limited minimax player (play_arena)
 
@@ -25,7 +26,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from betazero_amd.arena import play_arena  # noqa: E402
 from betazero_amd.augment import augment_examples  # noqa: E402
-from betazero_amd.engine import SelfPlayEngine, concat_examples  # noqa: E402
+from betazero_amd.engine import SelfPlayEngine, concat_device_examples  # noqa: E402
 from betazero_amd.net import DeviceNet, PolicyValueNet  # noqa: E402
 from betazero_amd.train import make_optimizer, refresh_device_net, train_step  # noqa: E402
 
@@ -48,11 +49,12 @@ def main():
     ap.add_argument("--final-depths", default="1,3,5", help="minimax depths the final net is also played against")
     ap.add_argument("--opening-plies", type=int, default=4, help="random legal moves before the arena players take over")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--fp32-train", action="store_true", help="train without bf16 autocast (A/B of the loss curve)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
     torch.manual_seed(args.seed)
-    rng = np.random.default_rng(args.seed)
+    gen = torch.Generator(device="cuda:0").manual_seed(args.seed)
     module = PolicyValueNet(args.channels, args.blocks, 64)
     opt = make_optimizer(module, lr=args.lr)
     bmax = max(args.games, args.arena_games)
@@ -82,19 +84,21 @@ def main():
         eng = SelfPlayEngine("reversi", args.games, args.sims, "net_bf16", dnet, temp_moves=args.temp_moves, openings=1,
                              seed=args.seed * 1000 + it, dirichlet_alpha=0.3, dirichlet_eps=0.25)
         plies = eng.run_iteration()
-        ex = eng.examples()
+        ex = eng.device_examples()   # finished games' rows, on the device
         winners, _ = eng.winners()
-        del eng
+        torch.cuda.synchronize()
         t_play = time.time() - t0
         t1 = time.time()
         aug = augment_examples(ex, dedupe=True)
+        del eng
         window = (window + [aug])[-args.window:]
-        data = concat_examples(window)
+        data = concat_device_examples(window)
         steps = max(1, int(args.epochs * len(data) / args.batch))
         losses = []
         for _ in range(steps):
-            idx = rng.integers(0, len(data), size=args.batch)
-            losses.append(train_step(module, opt, data, idx))
+            idx = torch.randint(0, len(data), (args.batch,), device=data.own.device, generator=gen)
+            losses.append(torch.stack(train_step(module, opt, data, idx, autocast=not args.fp32_train)))
+        losses = torch.stack(losses).cpu().numpy()  # one transfer per iteration, after the last step
         refresh_device_net(dnet, module)
         t_train = time.time() - t1
         head, tail = np.mean(losses[: max(1, steps // 10)], axis=0), np.mean(losses[-max(1, steps // 10):], axis=0)
