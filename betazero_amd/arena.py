@@ -42,6 +42,9 @@ def play_arena(game, n_games, sims, opponent_depth=4, evaluator="uniform", net=N
     Both players are deterministic, so without help there are only two distinct games (one per colour):
     `opening_plies` > 0 plays that many uniformly random legal moves (seeded) before the players take over, which
     makes the B games B different tests."""
+    if game != "ttt" and not 0 <= int(opponent_depth) <= 8:
+        raise ValueError(f"play_arena: opponent_depth must be in 0..8 (got {opponent_depth}): the minimax kernel keeps an "
+                         "explicit stack of that depth")
     _lib.require_gpu()
     L = _lib.lib()
     dev = torch.device(device)

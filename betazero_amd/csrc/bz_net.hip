@@ -286,7 +286,7 @@ template <int C_, int P_ = 512 / C_> struct Tw {
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
-#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT)) && !defined(BZ_EXPERIMENT)
+#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
 #ifdef BZ_EXP_STAMPS
@@ -572,7 +572,9 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     BZ_STAMP(t1);
     epilogue<G>(acc, out, second, bias, G::wt0(w), r, h);
     BZ_STAMP(t2);
-    __syncthreads();
+#ifndef BZ_EXP_NO_LAYER_BARRIER  // TIMING ONLY (results are wrong without it): the ceiling of any scheme that relaxes the
+    __syncthreads();             // per-layer barrier (per-row ready counters, ...) -- tools/exp_ab_barrier.sh, DESIGN.md 5
+#endif
     BZ_STAMP(t3);
     tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
 }
@@ -963,7 +965,9 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     BZ_STAMP(t1);
     epilogue(acc, out, second, sc, w, r, h);
     BZ_STAMP(t2);
-    __syncthreads();
+#ifndef BZ_EXP_NO_LAYER_BARRIER  // TIMING ONLY (results are wrong without it): the ceiling of any scheme that relaxes the
+    __syncthreads();             // per-layer barrier (per-row ready counters, ...) -- tools/exp_ab_barrier.sh, DESIGN.md 5
+#endif
     BZ_STAMP(t3);
     tacc[0] += t1 - t0; tacc[1] += t2 - t1; tacc[2] += t3 - t2;
 }

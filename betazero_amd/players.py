@@ -32,40 +32,6 @@ class ReversiRandomPlayer(ReversiPlayer):  # reversi_players.py:26-32
         return random.choice(moves) if moves else (None, None)
 
 
-class MinimaxPlayer(Player):
-    """Full-depth minimax for Tic-tac-toe over the Game API -- the strength yard-stick of
-    SURVEY 8(f) row 3.  Same decision rule as the reference's OptimalPlayer
-    (src/tic_tac_toe/players.py:30-70): random opening move on an empty board, otherwise the
-    first move with the best minimax score in generate_possible_moves() order."""
-
-    def __init__(self, symbol):
-        self.symbol = symbol
-        self._memo = {}
-
-    def get_move(self, board):
-        moves = board.generate_possible_moves()
-        if len(moves) == 9:
-            return random.choice(moves)
-        return self._minimax(board, True)[1]
-
-    def _minimax(self, board, is_max):
-        key = (board.board.tobytes(), is_max)
-        if key in self._memo:
-            return self._memo[key]
-        over, winner = board.is_game_over()
-        if over:
-            res = ((1 if winner == self.symbol else -1 if winner == -self.symbol else 0), None)
-        else:
-            best, best_move = (-2, None) if is_max else (2, None)
-            for mv in board.generate_possible_moves():
-                sc, _ = self._minimax(board.make_move(*mv, self.symbol if is_max else -self.symbol), not is_max)
-                if (is_max and sc > best) or (not is_max and sc < best):
-                    best, best_move = sc, mv
-            res = (best, best_move)
-        self._memo[key] = res
-        return res
-
-
 class OptimalPlayer(Player):
     """The reference's tic-tac-toe OptimalPlayer (src/tic_tac_toe/players.py:30-70) on the library's
     minimax (bz_ttt_minimax: the host build of the code the arena kernel runs): random opening move on an
@@ -96,8 +62,14 @@ class ReversiOptimalPlayer(ReversiPlayer):
     minimax on the stone difference, no pass rule inside the search, random.choice when no move scores above
     -inf -- on bz_reversi_minimax (0 <= max_depth <= 8)."""
 
+    MAX_DEPTH = 8  # the minimax kernel's explicit stack (bz_reversi_minimax); the reference's recursion has no limit
+
     def __init__(self, symbol, max_depth=4):
-        self.symbol, self.max_depth = symbol, max_depth
+        if not 0 <= int(max_depth) <= self.MAX_DEPTH:
+            raise ValueError(f"ReversiOptimalPlayer: max_depth must be in 0..{self.MAX_DEPTH} (got {max_depth}); the "
+                             "library's minimax keeps an explicit stack of that depth -- a known difference from the "
+                             "reference's unbounded recursion (INTEGRATION.md)")
+        self.symbol, self.max_depth = symbol, int(max_depth)
 
     def minimax(self, board, is_maximizing=True, depth=0):
         import ctypes as C

@@ -2,10 +2,11 @@
 TicTacToeHeadless (tic_tac_toe.py:6-34) and process_game_positions
 (SL/generate_training_games.py:12-23).
 
-Provenance note: this file is the API contract itself, so two pieces follow the reference's text line for
-line on purpose -- `__str__` (tic_tac_toe_board.py:7-15: the printed board is observable output) and the
-turn loop of `TicTacToeHeadless.play` (tic_tac_toe.py:13-34: the trajectory the data generator consumes).
-Everything else (bitboard state, rule calls through the C ABI) is this build's own."""
+Provenance note: this file is the API contract itself.  `__str__` follows the reference's text line for line on
+purpose (tic_tac_toe_board.py:7-15: the printed board is observable output).  `TicTacToeHeadless.play` keeps the
+reference's trajectory contract (tic_tac_toe.py:13-34: board.board before every move plus the final one, winner
+from is_game_over, "Invalid move: ..." on an illegal move) in this build's own loop.  Everything else (bitboard
+state, rule calls through the C ABI) is this build's own."""
 import ctypes as C
 
 import numpy as np
@@ -77,20 +78,21 @@ class TicTacToeHeadless:
         self.game_positions = []
 
     def play(self):
-        game_over, winner = False, None
-        while not game_over:
+        """the trajectory contract of tic_tac_toe.py:13-34: `game_positions` receives board.board before every move and
+        once more after the last one (len = plies + 1); an illegal move surfaces as ValueError("Invalid move: ...");
+        returns (game_positions, winner) with winner as is_game_over reports it"""
+        while True:
             self.game_positions.append(self.board.board)
-            player = self.players[self.current_player]
-            row, col = player.get_move(self.board)
+            finished, winner = self.board.is_game_over()
+            if finished:
+                return self.game_positions, winner
+            mover = self.current_player
+            row, col = self.players[mover].get_move(self.board)
             try:
-                self.board = self.board.make_move(row, col, self.current_player)
-            except ValueError as e:
-                raise ValueError(f"Invalid move: {e}")
-            game_over, winner = self.board.is_game_over()
-            self.current_player *= -1
-            if game_over:
-                self.game_positions.append(self.board.board)
-        return self.game_positions, winner
+                self.board = self.board.make_move(row, col, mover)
+            except ValueError as err:
+                raise ValueError(f"Invalid move: {err}")
+            self.current_player = -mover
 
 
 def process_game_positions(positions):

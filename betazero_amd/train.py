@@ -58,6 +58,73 @@ def train_step(module, optimizer, ex, idx=None, device="cuda:0", autocast=True):
     return loss.detach(), ce.detach(), mse.detach()
 
 
+class GraphedTrainStep:
+    """train_step() captured ONCE into a HIP graph and replayed: a step of a small net is ~150 short kernels (casts,
+    convolutions, point-wise ops, the optimiser), i.e. launch-bound in eager mode; the replay issues them back to back.
+    Same arithmetic as train_step (same module, Adam, bf16 autocast), fixed batch size.
+
+        step = GraphedTrainStep(module, lr=2e-3, batch=1024, na=65)
+        loss, ce, mse = step(examples, idx)      # idx: device index tensor of exactly `batch` rows
+
+    The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
+
+    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True):
+        self.module, self.batch, self.dev, self.autocast = module.to(device), batch, torch.device(device), autocast
+        self.optimizer = torch.optim.Adam(module.parameters(), lr=lr, capturable=True)
+        self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
+        self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)
+        self.pi = torch.full((batch, na), 1.0 / na, dtype=torch.float32, device=self.dev)
+        self.z = torch.zeros(batch, dtype=torch.int8, device=self.dev)
+        self.graph, self.out = None, None
+
+    def _step(self):
+        x = planes_from_bits(self.own, self.opp)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
+            logits, v = self.module(x)
+        logits, v = logits.float(), v.float()
+        ce = -(self.pi * F.log_softmax(logits, dim=1)).sum(1).mean()
+        mse = F.mse_loss(v, self.z.to(torch.float32))
+        loss = ce + mse
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        return torch.stack([loss.detach(), ce.detach(), mse.detach()])
+
+    def _capture(self):
+        """3 eager steps on a side stream (library handles, autotuning, optimiser state -- on all-zero boards and a
+        uniform pi with lr scaled to 0 so that the weights do not move), then the capture"""
+        self.module.train()
+        lrs = [g["lr"] for g in self.optimizer.param_groups]
+        for g in self.optimizer.param_groups:
+            g["lr"] = 0.0
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._step()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        for g, lr in zip(self.optimizer.param_groups, lrs):
+            g["lr"] = lr
+        for st in self.optimizer.state.values():  # the warm-up must not count as steps / leave moments behind
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    v.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._step()
+
+    def __call__(self, ex, idx):
+        assert idx.numel() == self.batch, "GraphedTrainStep replays a fixed batch size"
+        torch.index_select(ex.own, 0, idx, out=self.own)
+        torch.index_select(ex.opp, 0, idx, out=self.opp)
+        torch.index_select(ex.pi, 0, idx, out=self.pi)
+        torch.index_select(ex.z, 0, idx, out=self.z)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        return self.out.clone()
+
+
 def refresh_device_net(device_net, module):
     """push the trained weights into the HIP engine's net (bf16-rounded copy for the MFMA path)"""
     import copy

@@ -155,5 +155,5 @@ def test_minimax_yardstick_self_play_always_draws():
     import random
     random.seed(5)
     for _ in range(5):
-        positions, winner = bz.TicTacToeHeadless(bz.MinimaxPlayer(1), bz.MinimaxPlayer(-1)).play()
+        positions, winner = bz.TicTacToeHeadless(bz.OptimalPlayer(1), bz.OptimalPlayer(-1)).play()
         assert winner == 0 and len(positions) == 10

@@ -462,8 +462,10 @@ def test_device_resident_pipeline_gather_augment_train_never_visits_the_host(mon
 
         with monkeypatch.context() as mp:
             for name in ("cpu", "numpy", "tolist", "item"):
-                def raiser(self, *a, _n=name, **k):
-                    raise AssertionError(f"Tensor.{_n}() inside the device-resident pipeline")
+                def raiser(self, *a, _n=name, _orig=getattr(torch.Tensor, name), **k):
+                    if self.is_cuda:  # (Adam's step counter is a host tensor: its .item() moves nothing off the GPU)
+                        raise AssertionError(f"Tensor.{_n}() on a device tensor inside the device-resident pipeline")
+                    return _orig(self, *a, **k)
                 mp.setattr(torch.Tensor, name, raiser)
             dex = bd.gather_examples_device(engs)           # ONE all-gather (RCCL), unpacked where it lands
             daug = augment_examples(dex, dedupe=True)
@@ -483,6 +485,33 @@ def test_device_resident_pipeline_gather_augment_train_never_visits_the_host(mon
     d0 = augment_examples(engs[0].device_examples(), dedupe=True).cpu()
     assert np.array_equal(d0.own, host_aug.own) and np.array_equal(d0.opp, host_aug.opp) and np.array_equal(d0.act, host_aug.act)
     assert np.array_equal(d0.pi.view(np.uint32), host_aug.pi.view(np.uint32)) and np.array_equal(d0.z, host_aug.z)
+
+
+def test_graphed_train_step_equals_the_eager_step():
+    """GraphedTrainStep (the training step captured into a HIP graph and replayed) against train_step (eager) from
+    the same weights on the same batches: same losses step by step (same kernels, same order), and the weights move."""
+    import copy
+    from betazero_amd.engine import DeviceExamples
+    from betazero_amd.train import GraphedTrainStep, make_optimizer, train_step
+    rng = np.random.default_rng(11)
+    n = 512
+    own, opp = _positions(n, seed=91)
+    pi = rng.random((n, 65)).astype(np.float32); pi /= pi.sum(1, keepdims=True)
+    z = rng.integers(-1, 2, n).astype(np.int8)
+    from betazero_amd.engine import Examples
+    ex = DeviceExamples.from_host(Examples(own, opp, pi, z, np.ones(n, np.int8), np.zeros(n, np.uint8), np.arange(n),
+                                           np.zeros(n, np.int32), 8))
+    m1 = _net(64, 2, seed=5).cuda()
+    m2 = copy.deepcopy(m1)
+    opt = make_optimizer(m1, lr=1e-3)
+    g = GraphedTrainStep(m2, lr=1e-3, batch=128)
+    for s in range(5):
+        idx = torch.arange(128 * (s % 4), 128 * (s % 4) + 128, device="cuda:0")
+        a = torch.stack(train_step(m1, opt, ex, idx)).cpu().numpy()
+        b = g(ex, idx).cpu().numpy()
+        assert np.allclose(a, b, rtol=2e-3, atol=2e-3), (s, a, b)
+    w0 = _net(64, 2, seed=5).stem.weight
+    assert (m2.stem.weight.detach().cpu() - w0).abs().max() > 1e-4
 
 
 def test_training_step_closes_the_loop():
@@ -910,6 +939,42 @@ def test_cfg3_800_sims_bf16_net_search_close_to_oracle_bf16_emulation():
     assert max(tv) < 0.01 and same == B
 
 
+def test_cfg5_800_sims_fp8_net_search_close_to_oracle_fp8_emulation():
+    """BASELINE cfg 5 as SURVEY 7 reads it -- the fp8 net as the evaluator INSIDE the search: one 800-simulation search
+    of 8 games with the fp8 MFMA tower in the loop vs the oracle running the same search with its fp8-emulating net.
+    The two nets differ by ~1e-2 on the logits (accumulation order over e4m3 products), so the trees may part ways
+    sooner than with bf16; the visit distributions must stay close: total-variation distance of pi < 0.02 and the same
+    most-visited move."""
+    import threading
+    from betazero_amd.net import DeviceNet
+    from betazero_amd.quant import fake_quantize_fp8_
+    m = fake_quantize_fp8_(_net(128, 6))
+    B, sims = 8, 800
+    dn = DeviceNet.from_module(m, B)
+    eng = _engine("reversi", B, sims, "net_fp8", net=dn, temp_moves=8, openings=1, seed=0)
+    eng.reset_games()
+    own, opp, tm, _ = eng.positions()
+    eng.search()
+    N, _, P = eng.root_stats()
+    eng.status()
+    on = orc.Net(128, 6, 64, m.flat_params())
+    res = [None] * B
+
+    def work(g):
+        res[g] = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(tm[g]), sims, orc.EVAL_NET_FP8, net=on)
+    th = [threading.Thread(target=work, args=(g,)) for g in range(B)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    tv, same = [], 0
+    for g in range(B):
+        n, _, p, _ = res[g]
+        assert N[g].sum() == sims and np.abs(P[g] - p).max() < 1e-2  # root priors: softmax of logits that agree to ~1e-2
+        tv.append(0.5 * np.abs(N[g].astype(np.float64) - n.astype(np.float64)).sum() / sims)
+        same += int(np.argmax(N[g]) == np.argmax(n))
+    print("fp8 search vs oracle emulation: TV distance of pi per game", np.round(tv, 4), "same argmax", same, "of", B)
+    assert max(tv) < 0.02 and same == B
+
+
 def _stage_isolating_params(m, stage):
     """copy of module m in which conv stage `stage` (0 = stem, 2k+1 / 2k+2 = conv1 / conv2 of block k) is the
     LAST one that changes the activations: later blocks are zeroed (a zero block is the identity on the
@@ -952,6 +1017,32 @@ def test_net_bf16_every_conv_stage_on_its_own_vs_oracle():
     for a, b in zip(outs[:-1], outs[1:]):  # the construction really isolates stages: consecutive outputs differ
         assert np.abs(a - b).max() > 1e-3
     print("per-stage bf16 net: worst |dlogit| %.2e  |dv| %.2e" % worst)
+
+
+def test_net_bf16_every_conv_stage_on_its_own_throughput_shape_vs_oracle():
+    """the same 13 stage-isolating nets through the THROUGHPUT shape of the fused kernel (batches > 256 positions:
+    Tw<128, 4>, four positions per workgroup, row-tile units that skip the padding-row MFMAs -- the headline kernel):
+    301 positions (a ragged last workgroup), every 8th row and the last rows compared with the oracle per stage, so
+    the row-tile skip logic is pinned layer by layer and not only through the whole net."""
+    from betazero_amd.net import DeviceNet
+    m = _net(128, 6, bf16=True)
+    n = 301
+    own, opp = _positions(n, seed=13)
+    pick = np.unique(np.concatenate([np.arange(0, n, 8), np.arange(n - 5, n)]))
+    dn = DeviceNet.from_module(m, 512)
+    worst = (0.0, 0.0)
+    for stage in range(13):
+        mm = _stage_isolating_params(m, stage)
+        dn.update(mm.flat_params())
+        lg, v = dn.forward(_dev_u64(own), _dev_u64(opp), bf16=True)
+        olg, ov = orc.Net(128, 6, 64, mm.flat_params()).forward(own[pick], opp[pick], bf16=True)
+        el, ev = np.abs(lg.cpu().numpy()[pick] - olg).max(), np.abs(v.cpu().numpy()[pick] - ov).max()
+        worst = (max(worst[0], el), max(worst[1], ev))
+        assert el < 2e-3 and ev < 1e-3, (stage, el, ev)
+        # and the latency shape (<= 256 positions) gives the same bits for the same positions
+        l2, v2 = dn.forward(_dev_u64(own[:64]), _dev_u64(opp[:64]), bf16=True)
+        assert np.array_equal(l2.cpu().numpy().view(np.uint32), lg.cpu().numpy()[:64].view(np.uint32)), stage
+    print("per-stage bf16 net, throughput shape: worst |dlogit| %.2e  |dv| %.2e" % worst)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp8"])

@@ -78,12 +78,41 @@ def test_ttt_minimax_matches_reference_optimal_player_on_every_position():
     assert sc.value == -1
 
 
+class _GameApiMinimax:
+    """full-depth minimax over the Game API only (generate_possible_moves / make_move / is_game_over), memoised: an
+    independent statement of the reference's decision rule (src/tic_tac_toe/players.py:30-70: the first move with the
+    best score in generate_possible_moves() order) to hold the library's bz_ttt_minimax against"""
+
+    def __init__(self, symbol):
+        self.symbol, self._memo = symbol, {}
+
+    def get_move(self, board):
+        return self._minimax(board, True)[1]
+
+    def _minimax(self, board, is_max):
+        key = (board.board.tobytes(), is_max)
+        if key in self._memo:
+            return self._memo[key]
+        over, winner = board.is_game_over()
+        if over:
+            res = ((1 if winner == self.symbol else -1 if winner == -self.symbol else 0), None)
+        else:
+            best, best_move = (-2, None) if is_max else (2, None)
+            for mv in board.generate_possible_moves():
+                sc, _ = self._minimax(board.make_move(*mv, self.symbol if is_max else -self.symbol), not is_max)
+                if (is_max and sc > best) or (not is_max and sc < best):
+                    best, best_move = sc, mv
+            res = (best, best_move)
+        self._memo[key] = res
+        return res
+
+
 def test_ttt_optimal_player_class_never_loses_to_itself_and_matches_memoised_minimax():
     random.seed(3)
     for _ in range(5):
         positions, winner = bz.TicTacToeHeadless(bz.OptimalPlayer(1), bz.OptimalPlayer(-1)).play()
         assert winner == 0 and len(positions) == 10  # two perfect players draw in 9 plies (as in the reference's CSV)
-    # same decision as the Python MinimaxPlayer of round 1 (same rule, memoised) on random reachable positions
+    # same decision as a minimax written against the Game API alone, on random reachable positions
     rng = np.random.default_rng(0)
     for _ in range(40):
         t, cur = bz.TicTacToeBoard(), 1
@@ -95,7 +124,7 @@ def test_ttt_optimal_player_class_never_loses_to_itself_and_matches_memoised_min
             cur = -cur
         if t.is_game_over()[0]:
             continue
-        assert bz.OptimalPlayer(cur).get_move(t) == bz.MinimaxPlayer(cur).get_move(t)
+        assert bz.OptimalPlayer(cur).get_move(t) == _GameApiMinimax(cur).get_move(t)
 
 
 def _py_minimax(board, symbol, max_depth, is_max=True, depth=0):
@@ -137,3 +166,17 @@ def test_reversi_minimax_random_positions_vs_game_api_restatement():
         assert (gm, gs) == (-1 if mv is None else 8 * mv[0] + mv[1], exp_sc), (trial, size, depth, sym)
         n_none += mv is None
     assert n_none > 10
+
+
+def test_reversi_optimal_player_refuses_depths_the_kernel_cannot_hold():
+    """the library's minimax keeps an explicit stack of depth 8 (the reference recurses without a limit): a clear
+    ValueError at construction / at the arena call instead of a generic error at play time"""
+    import pytest
+    with pytest.raises(ValueError, match="max_depth"):
+        bz.ReversiOptimalPlayer(1, max_depth=9)
+    with pytest.raises(ValueError, match="max_depth"):
+        bz.ReversiOptimalPlayer(1, max_depth=-1)
+    assert bz.ReversiOptimalPlayer(1, max_depth=8).max_depth == 8
+    from betazero_amd.arena import play_arena
+    with pytest.raises(ValueError, match="opponent_depth"):
+        play_arena("reversi", 4, 8, opponent_depth=9)

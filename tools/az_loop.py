@@ -28,7 +28,7 @@ from betazero_amd.arena import play_arena  # noqa: E402
 from betazero_amd.augment import augment_examples  # noqa: E402
 from betazero_amd.engine import SelfPlayEngine, concat_device_examples  # noqa: E402
 from betazero_amd.net import DeviceNet, PolicyValueNet  # noqa: E402
-from betazero_amd.train import make_optimizer, refresh_device_net, train_step  # noqa: E402
+from betazero_amd.train import GraphedTrainStep, make_optimizer, refresh_device_net, train_step  # noqa: E402
 
 
 def main():
@@ -50,13 +50,15 @@ def main():
     ap.add_argument("--opening-plies", type=int, default=4, help="random legal moves before the arena players take over")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fp32-train", action="store_true", help="train without bf16 autocast (A/B of the loss curve)")
+    ap.add_argument("--eager-train", action="store_true", help="launch every kernel of a training step by itself instead of replaying the captured HIP graph")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
     torch.manual_seed(args.seed)
     gen = torch.Generator(device="cuda:0").manual_seed(args.seed)
     module = PolicyValueNet(args.channels, args.blocks, 64)
-    opt = make_optimizer(module, lr=args.lr)
+    opt = make_optimizer(module, lr=args.lr) if args.eager_train else None
+    graphed = None if args.eager_train else GraphedTrainStep(module, lr=args.lr, batch=args.batch, autocast=not args.fp32_train)
     bmax = max(args.games, args.arena_games)
     dnet = DeviceNet.from_module(module.round_to_bf16_(), bmax)
     lines = []
@@ -97,7 +99,10 @@ def main():
         losses = []
         for _ in range(steps):
             idx = torch.randint(0, len(data), (args.batch,), device=data.own.device, generator=gen)
-            losses.append(torch.stack(train_step(module, opt, data, idx, autocast=not args.fp32_train)))
+            if graphed is not None:
+                losses.append(graphed(data, idx))
+            else:
+                losses.append(torch.stack(train_step(module, opt, data, idx, autocast=not args.fp32_train)))
         losses = torch.stack(losses).cpu().numpy()  # one transfer per iteration, after the last step
         refresh_device_net(dnet, module)
         t_train = time.time() - t1
