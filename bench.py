@@ -43,7 +43,7 @@ NET_FLOP_PER_POS = 226.86e6                           # stem + t
 MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md (fp8: 2x)
 HBM_PEAK_GBS = 8000.0
 PLIES_PER_GAME = 58                                   # searched moves per cfg-3 game (60 - 2 opening plies)
-PMC_TRAFFIC = ("profiles/r02_pmc_traffic.json", "profiles/r01_pmc_traffic.json")
+PMC_TRAFFIC = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
 
 
 def tree_bytes(c):
@@ -612,16 +612,22 @@ def run_reversi(ctx, args, B, sims, K, W):
             "busy_ms": union_ms, "avg_launch_ms": union_ms / max(launches, 1),
             "shared_time": {"avg_launch_ms": sum_ms / max(launches, 1), "concurrent_launches": sum_ms / union_ms,
                             "tflops_per_launch": flop_per_launch / (sum_ms / max(launches, 1) * 1e-3) / 1e12}}
+        # HBM traffic of the tower: PMC counters cannot run inside this (timed) process, so the figure comes from the
+        # committed counter passes of the SAME command (tools/profile_round.sh pmc_bench: FETCH_SIZE / WRITE_SIZE, each in
+        # its own run; gfx950 fetch correction applied); it is attached only when it was measured at this run's shape
+        # (precision, pipelines) and says at how many positions per launch
+        ppl = flop_per_launch / NET_FLOP_PER_POS
         for path in PMC_TRAFFIC:
             try:
                 tr = json.load(open(os.path.join(ROOT, path)))["k_tower_bf16"]
-                if prec == "bf16":
-                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({path}: " \
-                                                        f"{tr.get('positions_per_launch', 4096)} positions per launch)"
-                break
             except Exception:
                 continue
+            tp = float(tr.get("positions_per_launch", 4096))
+            if prec == "bf16" and abs(tp - ppl) <= 0.1 * ppl:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({path}: "
+                                                     f"{tp:.0f} positions per launch; this run: {ppl:.0f})")
+                break
         tb = tree_bytes(cnt) * (prof_steps / K if (args.mode == "steady" and prof_steps < K) else 1.0)  # the timed steps' share
         t_union, t_sum = _lib.profile_union_ms("select")
         out["roofline_tree"] = {"bound": "hbm", "kernels": "k_tree_step (expand + backup + select, 16 lanes per game)",

@@ -211,36 +211,54 @@ __device__ __forceinline__ u64 rev_flips_carry(u64 me, u64 you, int a, const Ray
     return f | ((u64)__brev((u32)g) << 32) | (u64)__brev((u32)(g >> 32));
 }
 
-// one env step; a placement is legal iff the cell is empty and it flips something, so the
-// mover's full legal mask is only needed for the (rare) pass action
-__device__ __forceinline__ void reversi_step_one(u64 me, u64 you, int a, u64 valid, const RayEnt* tab, u64& cown, u64& copp,
-                                                 u64& nl, uint8_t& st, int8_t& w) {
-    cown = me; copp = you; st = BZ_ST_ILLEGAL; w = 0;
-    bool ok;
-    if (a == kPass) {
-        nl = rev_legal(me, you, valid);
-        ok = nl == 0;
-        if (ok) { cown = you; copp = me; }
-    } else {
-        u64 m = a < 64 ? (1ULL << a) & valid : 0ULL;
-        u64 f = (m & ~(me | you)) ? rev_flips_carry(me, you, a, tab) : 0ULL;
-        ok = f != 0;
-        if (ok) { cown = you & ~f; copp = me | m | f; }
-        else nl = rev_legal(me, you, valid);
+// One env step, split in two so that the batch kernel can run the RARE part once per lane instead of once per game:
+//  * step_main: the move itself and the next mover's legal mask (always needed).  A placement is legal iff the cell is
+//    empty and it flips something, so the mover's own legal mask is not computed.  Returns true when one more legal
+//    mask J = rev_legal(jx, jy) is needed to finish: to verify a pass (the mover must have no move: J = legal(me, you)),
+//    or, when the next mover has no move, to tell MUST_PASS from TERMINAL (J = legal(copp, cown)).  For a pass the two
+//    are the same mask.
+//  * step_finish: the status / winner from J.
+// With 4 games per lane and 64 lanes, "rare" (a per cent of the games) would otherwise mean "in nearly every wave, for
+// every one of the 4 game slots": ~80 extra instructions per game.
+struct StepOut { u64 cown, copp, nl; uint8_t st; int8_t w; };
+__device__ __forceinline__ bool step_main(u64 me, u64 you, int a, u64 valid, const RayEnt* tab, StepOut& o, u64& jx, u64& jy) {
+    o.cown = me; o.copp = you; o.st = BZ_ST_ILLEGAL; o.w = 0; o.nl = 0;
+    jx = me; jy = you;
+    if (a == kPass) {  // tentatively accepted; step_finish checks that the mover really had no move
+        o.cown = you; o.copp = me;
+        o.nl = rev_legal(o.cown, o.copp, valid);
+        return true;
     }
-    if (ok) {
-        nl = rev_legal(cown, copp, valid);
-        st = BZ_ST_RUNNING;
-        if (nl == 0) {
-            if (rev_legal(copp, cown, valid) == 0) {
-                st = BZ_ST_TERMINAL;
-                int d = popc64(copp) - popc64(cown);  // copp = the player who just moved
-                w = (int8_t)(d > 0 ? 1 : (d < 0 ? -1 : 0));
-            } else {
-                st = BZ_ST_MUST_PASS;
-            }
+    const u64 m = a < 64 ? (1ULL << a) & valid : 0ULL;
+    const u64 f = (m & ~(me | you)) ? rev_flips_carry(me, you, a, tab) : 0ULL;
+    if (f == 0) { o.nl = rev_legal(me, you, valid); return false; }  // illegal placement: position unchanged
+    o.cown = you & ~f; o.copp = me | m | f;
+    o.nl = rev_legal(o.cown, o.copp, valid);
+    o.st = BZ_ST_RUNNING;
+    jx = o.copp; jy = o.cown;
+    return o.nl == 0;
+}
+__device__ __forceinline__ void step_finish(u64 me, u64 you, int a, u64 J, StepOut& o) {
+    if (a == kPass && J != 0) {  // the mover had a move: the pass is illegal, nothing changes
+        o.cown = me; o.copp = you; o.nl = J; o.st = BZ_ST_ILLEGAL; o.w = 0;
+        return;
+    }
+    o.st = BZ_ST_RUNNING;
+    if (o.nl == 0) {
+        if (J == 0) {
+            o.st = BZ_ST_TERMINAL;
+            const int d = popc64(o.copp) - popc64(o.cown);  // copp = the player who just moved
+            o.w = (int8_t)(d > 0 ? 1 : (d < 0 ? -1 : 0));
+        } else {
+            o.st = BZ_ST_MUST_PASS;
         }
     }
+}
+__device__ __forceinline__ void reversi_step_one(u64 me, u64 you, int a, u64 valid, const RayEnt* tab, u64& cown, u64& copp,
+                                                 u64& nl, uint8_t& st, int8_t& w) {
+    StepOut o; u64 jx, jy;
+    if (step_main(me, you, a, valid, tab, o, jx, jy)) step_finish(me, you, a, rev_legal(jx, jy, valid), o);
+    cown = o.cown; copp = o.copp; nl = o.nl; st = o.st; w = o.w;
 }
 
 // 4 games per lane: 2 x 16-byte loads per bitboard array, 4-byte loads/stores of the byte arrays
@@ -260,17 +278,29 @@ __global__ void __launch_bounds__(256) k_reversi_step(const u64* __restrict__ ow
         uchar4 ac = reinterpret_cast<const uchar4*>(action)[i];
         u64 me[4] = {oa.x, oa.y, ob.x, ob.y}, you[4] = {pa.x, pa.y, pb.x, pb.y};
         int aa[4] = {ac.x, ac.y, ac.z, ac.w};
-        u64 co[4], cp[4], nl[4]; uint8_t st[4]; int8_t w[4];
+        StepOut o[4]; u64 jx[4], jy[4];
+        unsigned need = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) reversi_step_one(me[k], you[k], aa[k], valid, tab, co[k], cp[k], nl[k], st[k], w[k]);
+        for (int k = 0; k < 4; ++k) need |= step_main(me[k], you[k], aa[k], valid, tab, o[k], jx[k], jy[k]) ? 1u << k : 0u;
+        // the games that need one more legal mask, one per lane per round (most lanes: none; a second round is very rare)
+        while (__builtin_amdgcn_ballot_w64(need != 0)) {
+            const int k = need ? __ffs(need) - 1 : 0;
+            const u64 x = k == 0 ? jx[0] : (k == 1 ? jx[1] : (k == 2 ? jx[2] : jx[3]));
+            const u64 y = k == 0 ? jy[0] : (k == 1 ? jy[1] : (k == 2 ? jy[2] : jy[3]));
+            const u64 J = rev_legal(x, y, valid);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (need && k == q) step_finish(me[q], you[q], aa[q], J, o[q]);
+            need &= need - 1u;
+        }
         ulonglong2* on2 = reinterpret_cast<ulonglong2*>(own_next) + 2 * i;
         ulonglong2* pn2 = reinterpret_cast<ulonglong2*>(opp_next) + 2 * i;
         ulonglong2* ln2 = reinterpret_cast<ulonglong2*>(legal_next) + 2 * i;
-        on2[0] = make_ulonglong2(co[0], co[1]); on2[1] = make_ulonglong2(co[2], co[3]);
-        pn2[0] = make_ulonglong2(cp[0], cp[1]); pn2[1] = make_ulonglong2(cp[2], cp[3]);
-        ln2[0] = make_ulonglong2(nl[0], nl[1]); ln2[1] = make_ulonglong2(nl[2], nl[3]);
-        reinterpret_cast<uchar4*>(status)[i] = make_uchar4(st[0], st[1], st[2], st[3]);
-        reinterpret_cast<char4*>(winner)[i] = make_char4(w[0], w[1], w[2], w[3]);
+        on2[0] = make_ulonglong2(o[0].cown, o[1].cown); on2[1] = make_ulonglong2(o[2].cown, o[3].cown);
+        pn2[0] = make_ulonglong2(o[0].copp, o[1].copp); pn2[1] = make_ulonglong2(o[2].copp, o[3].copp);
+        ln2[0] = make_ulonglong2(o[0].nl, o[1].nl); ln2[1] = make_ulonglong2(o[2].nl, o[3].nl);
+        reinterpret_cast<uchar4*>(status)[i] = make_uchar4(o[0].st, o[1].st, o[2].st, o[3].st);
+        reinterpret_cast<char4*>(winner)[i] = make_char4(o[0].w, o[1].w, o[2].w, o[3].w);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // ragged tail
         int64_t i = (n4 << 2) + threadIdx.x;

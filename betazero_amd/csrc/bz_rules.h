@@ -52,10 +52,31 @@ BZ_HD u64 rev_moves_dir(u64 own, u64 o, int s) {
     return (fl << s) | (fr >> s);
 }
 
+BZ_HD u64 brev64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    return __builtin_bitreverse64(x);
+#endif
+}
+
+// the east / west pair by carry propagation (an addition carries in the +1 direction, which IS east): with oh = the
+// opponent's stones in columns 1..6, x = the stones of oh whose west neighbour is the mover's, x + oh clears every run
+// of opponent stones that starts at an x and sets the cell just past it -- the candidate (runs that start nowhere near
+// the mover are left alone and masked off; a carry cannot leave its row because column 7 is never in oh).  West is east
+// on the bit-reversed boards (bit i <-> 63 - i; the column mask is symmetric).  8 + 14 instructions against 2 x 24 for
+// the parallel-prefix fill; the caller masks the result with the empty cells.
+BZ_HD u64 rev_moves_ew(u64 own, u64 oh) {
+    const u64 e = ((oh & (own << 1)) + oh) & ~oh;
+    const u64 ro = brev64(oh), rp = brev64(own);
+    const u64 w = ((ro & (rp << 1)) + ro) & ~ro;
+    return e | brev64(w);
+}
+
 // generate_possible_moves(player) as a mask; own = player's stones
 BZ_HD u64 rev_legal(u64 own, u64 opp, u64 valid) {
     u64 oh = opp & kInner;
-    u64 m = rev_moves_dir(own, oh, 1) | rev_moves_dir(own, opp, 8) | rev_moves_dir(own, oh, 7) |
+    u64 m = rev_moves_ew(own, oh) | rev_moves_dir(own, opp, 8) | rev_moves_dir(own, oh, 7) |
             rev_moves_dir(own, oh, 9);
     return m & ~(own | opp) & valid;
 }

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_pmc_traffic.json from the summarised counter passes of tools/profile_round.sh:
+HBM bytes per launch of the tower from FETCH_SIZE / WRITE_SIZE (separate --pmc passes; gfx950: FETCH_SIZE counts 128-byte
+requests at 64 bytes -- MI355X_MICROARCH.md, HBM section -- so hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024), at the
+bench's own batch (pmc_bench_*: the default two-pipeline command) and at 4096 positions (pmc_tower_*: tools/bench_net.py).
+usage: python tools/make_traffic_json.py r03 [summary-dir]   (default summary dir: profiles/)"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+
+
+def mean(name, counter, kernel):
+    path = os.path.join(src, f"{tag}_{name}_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if r["Counter"] == counter and kernel in r["Kernel"]:
+            return float(r["MeanValue"]), int(r["Dispatches"])
+    return None
+
+
+out = {"source": f"tools/profile_round.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
+                 "values in KB per launch, mean over launches",
+       "correction": "MI355X_MICROARCH.md HBM section: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts "
+                     "128-B requests at 64 B)"}
+for key, name, ppl_file in (("k_tower_bf16", "pmc_bench", "pmc_bench_fetch.json"), ("k_tower_bf16@4096", "pmc_tower", None)):
+    f, w = mean(name + "_fetch", "FETCH_SIZE", "k_tower_bf16"), mean(name + "_write", "WRITE_SIZE", "k_tower_bf16")
+    if not f or not w:
+        continue
+    ent = {"fetch_kb": f[0], "write_kb": w[0], "hbm_bytes_per_launch": int((2 * f[0] + w[0]) * 1024), "launches": f[1]}
+    if ppl_file:
+        try:  # positions per launch of the very run the counters come from
+            d = json.load(open(os.path.join(src, f"{tag}_{ppl_file}")))
+            ent["positions_per_launch"] = d["roofline"]["positions_per_launch"]
+            ent["command"] = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (two pipelines of 2048 games)"
+        except Exception:
+            pass
+    else:
+        ent["positions_per_launch"] = 4096
+        ent["command"] = "python3 tools/bench_net.py 4096 60"
+    out[key] = ent
+path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+json.dump(out, open(path, "w"), indent=1)
+print(open(path).read())

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Evidence collection for one round, run on the GPU box through gpurun:
-#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02 [sections]'
+#   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/profile_round.sh r03 [sections]'
 # Raw rocprofv3 output goes to gpurun_out/<tag>prof/; tools/summarize_prof.py then writes the small files
 # that are committed under profiles/.  Counters are collected in their own passes (--pmc with
 # --kernel-trace only), the program sits directly after `--` (no env/bash hop under the profiler).
@@ -26,6 +26,12 @@ if has pmc_tower; then
   run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_tower_write" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_write.txt" 2>&1
   run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_tower_tcc" -o t -- python3 tools/bench_net.py 4096 60 > "$OUT/pmc_tower_tcc.txt" 2>&1
 fi
+if has pmc_bench; then
+  # HBM traffic of the tower AT THE BENCH'S OWN BATCH (two pipelines of 2048 games: ~1850 packed positions per launch):
+  # the same command as the bench line, counters in their own passes
+  run 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_bench_fetch" -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_bench_fetch.json" 2> "$OUT/pmc_bench_fetch.err"
+  run 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_bench_write" -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_bench_write.json" 2> "$OUT/pmc_bench_write.err"
+fi
 if has pmc_ttt; then
   for gw in 2 0; do   # 2 = the TTT-specialised fused search, 0 = the generic fused kernel (the "before": --ttt-lanes -1)
     if [ $gw = 0 ]; then LANES="--ttt-lanes -1"; else LANES="--ttt-lanes $gw"; fi
@@ -39,6 +45,12 @@ if has pmc_env; then
   run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT/pmc_env_sq" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_sq.txt" 2>&1
   run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_env_fetch" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_fetch.txt" 2>&1
   run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_env_write" -o t -- python3 tools/bench_env.py > "$OUT/pmc_env_write.txt" 2>&1
+fi
+if has tree; then
+  # k_tree_step: per-simulation durations from the kernel trace (fixed cost vs cost per level), stamps per phase
+  run 600 bash tools/exp_tree.sh "${TAG}" > "$OUT/tree_trace.txt" 2>&1
+  SO=$(python3 -c "from betazero_amd import build; print(build.build_variant('treestamps', ['-DBZ_EXP_TREE_STAMPS']))")
+  BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 run 300 python3 tools/exp_tree_stamps.py 800 > "$OUT/tree_stamps.txt" 2>&1
 fi
 if has pmc_tree; then
   # cfg 3's tree step (hidden behind the net in the bench): a short single-pipeline run, counters per launch
@@ -57,6 +69,7 @@ if has clock; then
   TAPS=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_taps_bf16.txt" 2>&1   # cycles per conv tap (stamped variant)
   ZERO=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16_zero_weights.txt" 2>&1   # same instruction stream, operands that toggle nothing
   run 300 bash tools/exp_ab_rowt.sh > "$OUT/ab_tower_rowt.txt" 2>&1            # row-tile units vs position-major, interleaved
+  run 300 bash tools/exp_ab_barrier.sh > "$OUT/ab_tower_barrier.txt" 2>&1      # ceiling of relaxing the per-layer barrier
 fi
 if has ab; then
   # cost of the in-library kernel timers on `value`, and 1 / 2 / 3 pipelines, interleaved on ONE device
