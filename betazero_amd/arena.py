@@ -148,8 +148,12 @@ def play_arena(game, n_games, sims, opponent_depth=4, evaluator="uniform", net=N
                 _lib.check(L.bz_reversi_step_batch_sized(own.data_ptr(), opp.data_ptr(), safe.data_ptr(), B, size,
                                                          own_n.data_ptr(), opp_n.data_ptr(), legal_n.data_ptr(),
                                                          status.data_ptr(), win_n.data_ptr(), st()))
-        if bool((active & (status == _lib.ST_ILLEGAL)).any()):
-            raise RuntimeError("arena: a player produced an illegal move")
+        bad = active & (status == _lib.ST_ILLEGAL)
+        if bool(bad.any()):
+            g = int(bad.nonzero()[0])
+            who = "MCTS" if bool((to_move == mcts_colour)[g]) and ply >= opening_plies else ("opening" if ply < opening_plies else "minimax")
+            raise RuntimeError(f"arena: a player produced an illegal move: game {g}, ply {ply}, {who} to move, own "
+                               f"{int(own[g]) & (2**64 - 1):#018x} opp {int(opp[g]) & (2**64 - 1):#018x} action {int(action[g])}")
         term = active & (status == _lib.ST_TERMINAL)
         # TTT reports the absolute winner; Reversi the result for the player who just moved
         winner = torch.where(term, win_n if ttt else (win_n * to_move).to(torch.int8), winner)

@@ -68,14 +68,11 @@ class GraphedTrainStep:
 
     The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
 
-    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, channels_last=True):
-        # channels-last activations / weights: MIOpen's bf16 convolutions on [batch, C, 8, 8] run ~20 % faster that way
-        # (tools/bench_train.py); parameter VALUES and flat_params() order are unaffected
-        self.cl = channels_last
-        module.to(device)
-        if channels_last:
-            module.to(memory_format=torch.channels_last)
-        self.module, self.batch, self.dev, self.autocast = module, batch, torch.device(device), autocast
+    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True):
+        # (NCHW on purpose: channels-last convolutions measured ~20 % faster per step in tools/bench_train.py, but the
+        # closed loop then failed to learn the value head in one run and produced non-finite weights in two others --
+        # profiles/r03_az_loop_channels_last_failure.txt -- so that layout is not offered)
+        self.module, self.batch, self.dev, self.autocast = module.to(device), batch, torch.device(device), autocast
         self.optimizer = torch.optim.Adam(module.parameters(), lr=lr, capturable=True)
         self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)
@@ -85,8 +82,6 @@ class GraphedTrainStep:
 
     def _step(self):
         x = planes_from_bits(self.own, self.opp)
-        if self.cl:
-            x = x.contiguous(memory_format=torch.channels_last)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
             logits, v = self.module(x)
         logits, v = logits.float(), v.float()

@@ -69,8 +69,13 @@ def main():
 
     def arena(evaluator, net, depth=None):
         t0 = time.time()
-        res = play_arena("reversi", args.arena_games, args.arena_sims, opponent_depth=depth or args.depth, evaluator=evaluator,
-                         net=net, seed=args.seed, opening_plies=args.opening_plies)
+        try:
+            res = play_arena("reversi", args.arena_games, args.arena_sims, opponent_depth=depth or args.depth, evaluator=evaluator,
+                             net=net, seed=args.seed, opening_plies=args.opening_plies)
+        except RuntimeError:  # keep the weights that were in play for a post-mortem
+            if args.out:
+                np.save(args.out + ".failed_params.npy", module.flat_params())
+            raise
         s = res.summary()
         s["score"] = round((s["wins"] + 0.5 * s["draws"]) / s["games"], 4)
         s["seconds"] = round(time.time() - t0, 1)
@@ -104,6 +109,9 @@ def main():
             else:
                 losses.append(torch.stack(train_step(module, opt, data, idx, autocast=not args.fp32_train)))
         losses = torch.stack(losses).cpu().numpy()  # one transfer per iteration, after the last step
+        if not np.isfinite(losses).all():
+            raise RuntimeError(f"training diverged in iteration {it}: first non-finite loss at step "
+                               f"{int(np.argmax(~np.isfinite(losses).all(1)))} of {steps}")
         refresh_device_net(dnet, module)
         t_train = time.time() - t1
         head, tail = np.mean(losses[: max(1, steps // 10)], axis=0), np.mean(losses[-max(1, steps // 10):], axis=0)
