@@ -1213,6 +1213,38 @@ def test_dirichlet_root_noise_search_and_selfplay_vs_oracle_bitexact(gw):
         assert np.array_equal(ex.act[mk], r["act"]) and np.array_equal(ex.pi[mk].view(np.uint32), r["pi"].view(np.uint32))
 
 
+def test_external_evaluator_with_root_noise_vs_oracle():
+    """Dirichlet root noise used to be drawn only inside bz_engine_search, so step-API callers
+    (search_external, BZ_EVAL_EXTERNAL) silently searched on clean priors although the config asked for noise.
+    bz_engine_root_noise is now an entry point and search_external calls it where bz_engine_search does: root N / W / P of
+    a noisy search driven through the step API with caller-filled (hash) logits equal the oracle's noisy search."""
+    own, opp = _positions(6, seed=77)
+    tm = np.array([1, -1, 1, -1, 1, -1], np.int8)
+    sims = 48
+    eng = _engine("reversi", 6, sims, "external", seed=9, game_id_base=200, dirichlet_alpha=0.4, dirichlet_eps=0.25)
+    eng.set_roots(own, opp, tm)
+
+    def hash_eval(o, p, kind):
+        torch.cuda.synchronize()
+        oc, pc = o.cpu().numpy().view(np.uint64), p.cpu().numpy().view(np.uint64)
+        lg, v = np.zeros((6, eng.na), np.float32), np.zeros(6, np.float32)
+        for g in range(6):
+            lg[g], v[g] = orc.eval_hash(int(oc[g]), int(pc[g]), eng.na)
+        return torch.from_numpy(lg).cuda(), torch.from_numpy(v).cuda()
+    eng.search_external(hash_eval)
+    N, W, P = eng.root_stats()
+    eng.status()
+    clean = 0
+    for g in range(6):
+        n, w, p, _ = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(tm[g]), sims, orc.EVAL_HASH,
+                                     dir_alpha=0.4, dir_eps=0.25, seed=9, gid=200 + g, ply=0)
+        assert np.array_equal(N[g], n) and np.array_equal(W[g].view(np.uint32), w.view(np.uint32)), g
+        assert np.array_equal(P[g].view(np.uint32), p.view(np.uint32)), g
+        _, _, p0, _ = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(tm[g]), sims, orc.EVAL_HASH)
+        clean += int(np.array_equal(p, p0))
+    assert clean <= 1  # the noise really moved the priors (a root with a single move keeps P = 1)
+
+
 def test_subtree_reuse_selfplay_vs_oracle_bitexact():
     """subtree reuse: the chosen child's subtree is copied to the front of the other arena and searched on
     (`sims` new simulations on top of the retained statistics), through passes, with the arena-capacity rule, with and
