@@ -61,7 +61,9 @@ enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDE
 // NEVAL[2]: packed-leaf counters, double-buffered by simulation parity (the tree step that
 // packs into one buffer zeroes the other, so no extra reset launch is needed)
 enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_NEVAL = 4, FLAG_N = 8 };
-enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8 };
+// ERR_EVAL_NONFINITE: the evaluator handed back a NaN / infinity (a diverged net, an external evaluator's bug): the
+// softmax of such a row is NaN, every PUCT comparison with it is false and the search would quietly walk garbage
+enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, ERR_DEPTH = 8, ERR_EVAL_NONFINITE = 16 };
 
 struct __attribute__((aligned(16))) PathEnt { u32 eidx; u32 w0; float W; u32 pad; };
 
@@ -451,6 +453,7 @@ __device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u3
                 s = __shfl(part, kGW - 1, kGW);
             }
         }
+        if (sub == 0 && !(s >= 1.0f && s <= 3.0e38f)) atomicOr(&E.flags[FLAG_ERR], ERR_EVAL_NONFINITE);  // (the maximum's term is exactly 1)
         float pr[kCH];
 #pragma unroll
         for (int k = 0; k < kCH; ++k) pr[k] = a[k] >= 0 ? fdiv(ex[k], s) : 0.0f;
@@ -723,6 +726,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
             if (kind == LEAF_EVAL) {  // ---- round trip 2: the evaluator's row
                 LogitSrc ls; ls.kind = BZ_EVAL_EXTERNAL; ls.h = 0; ls.row = E.logits + (size_t)row * G::NA;
                 v = E.value[row];
+                if (sub == 0 && !(v >= -3.0e38f && v <= 3.0e38f)) atomicOr(&E.flags[FLAG_ERR], ERR_EVAL_NONFINITE);
                 n = dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c, st);
                 if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.root_n[g] = (u32)n; }
                 if (leaf == 0) { root_n = n; pre_ok = false; }  // the root's edges did not exist when re0 was fetched

@@ -200,7 +200,10 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bz_engine_status(self.h, self._stream(), C.byref(a), C.byref(f), C.byref(e)))
         if e.value:
-            raise RuntimeError(f"bz_engine error flags 0x{e.value:x}")
+            names = [n for bit, n in ((1, "edge arena overflow"), (2, "terminal root"), (4, "example buffer overflow"),
+                                      (8, "walk deeper than the path buffer"),
+                                      (16, "the evaluator returned a non-finite logit or value")) if e.value & bit]
+            raise RuntimeError(f"bz_engine error flags 0x{e.value:x}: " + ", ".join(names))
         return a.value, f.value
 
     def root_stats(self):

@@ -274,7 +274,15 @@ int32_t bz_engine_root_stats(bz_engine* e, void* stream);
 /* M5: pi, move choice, example row, env step, pass rule, terminal handling.
  * restart != 0: a finished slot starts its next game (next round) at once. */
 int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream);
-/* synchronises the stream; number of active slots / finished games so far */
+/* synchronises the stream; number of active slots / finished games so far.  error_flags (sticky until the next
+ * reset_games / set_roots): 1 = a game's edge arena overflowed, 2 = a root position was already terminal, 4 = more example
+ * rows than t_max, 8 = a walk deeper than the path buffer, 16 = the evaluator returned a non-finite logit or value (the
+ * search results of that move are meaningless) */
+#define BZ_ENGINE_ERR_EDGE_OVERFLOW 1
+#define BZ_ENGINE_ERR_TERMINAL_ROOT 2
+#define BZ_ENGINE_ERR_EXAMPLE_OVERFLOW 4
+#define BZ_ENGINE_ERR_DEPTH 8
+#define BZ_ENGINE_ERR_EVAL_NONFINITE 16
 int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
                          int32_t* error_flags);
 /* aliases under the names SURVEY.md 8(b) lists: select / expand+backup of one simulation, and

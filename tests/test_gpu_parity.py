@@ -1245,6 +1245,47 @@ def test_external_evaluator_with_root_noise_vs_oracle():
     assert clean <= 1  # the noise really moved the priors (a root with a single move keeps P = 1)
 
 
+def test_non_finite_evaluator_output_raises_instead_of_walking_garbage():
+    """a NaN / infinite logit or value makes every PUCT comparison false; the search would quietly pick edge 0 with a
+    zeroed header, overwrite root edges and report visits on action 0 (seen once with a diverged net: the arena then
+    played an illegal move).  The expansion now raises an engine error flag, which status() turns into an exception."""
+    own, opp = _positions(4, seed=5)
+    tm = np.ones(4, np.int8)
+    for what in ("nan_logit", "inf_logit", "nan_value"):
+        eng = _engine("reversi", 4, 8, "external")
+        eng.set_roots(own, opp, tm)
+
+        def bad(o, p, kind, what=what):
+            lg = torch.zeros((4, eng.na), device="cuda:0")
+            v = torch.zeros(4, device="cuda:0")
+            if what == "nan_logit":
+                lg[2, :] = float("nan")
+            elif what == "inf_logit":
+                lg[1, :] = float("inf")
+            else:
+                v[3] = float("nan")
+            return lg, v
+        eng.search_external(bad)
+        with pytest.raises(RuntimeError, match="non-finite"):
+            eng.status()
+    eng = _engine("reversi", 4, 8, "external")   # and a clean evaluator raises nothing
+    eng.set_roots(own, opp, tm)
+    eng.search_external(lambda o, p, k: (torch.zeros((4, eng.na), device="cuda:0"), torch.zeros(4, device="cuda:0")))
+    eng.status()
+
+
+def test_arena_both_players_only_ever_play_legal_moves_stress():
+    """4096 concurrent arena games from seeded random openings, MCTS (hash / uniform evaluators) against the minimax
+    kernel: every move of either side goes through the batched env step (legality from the carry-propagation flips),
+    which must never flag one -- three rule implementations (tree kernels, minimax kernel, env step) agreeing on
+    positions none of the fixtures holds."""
+    from betazero_amd.arena import play_arena
+    for seed, ev, depth, sims in ((0, "uniform", 2, 16), (1, "hash", 3, 24)):
+        r = play_arena("reversi", 2048, sims, opponent_depth=depth, evaluator=ev, seed=seed, opening_plies=6 + seed)
+        s = r.summary()
+        assert s["games"] == 2048 and s["wins"] + s["draws"] + s["losses"] == 2048
+
+
 def test_subtree_reuse_selfplay_vs_oracle_bitexact():
     """subtree reuse: the chosen child's subtree is copied to the front of the other arena and searched on
     (`sims` new simulations on top of the retained statistics), through passes, with the arena-capacity rule, with and

@@ -82,3 +82,39 @@ def test_dedupe_is_exact_under_key_collisions():
     # with honest keys (equal content <=> equal key) it is exactly "first occurrence, insertion order"
     key2 = torch.tensor([10, 11, 10, 12, 11, 13], dtype=torch.int64)
     assert _first_occurrences(key2, own, opp, pi).tolist() == [0, 1, 3, 5]
+
+
+def test_device_examples_unpack_equals_host_unpack_on_cpu_tensors():
+    """unpack_example_block_device (views from the engine geometry, game ids from the header as tensor scalars, row
+    selection by nonzero) against unpack_example_block (header parsed on the host) on a block of the engine's exact
+    layout -- the function is device-agnostic, so the CPU suite can pin it"""
+    import torch
+    from betazero_amd.engine import (DeviceExamples, build_example_block, concat_device_examples, unpack_example_block,
+                                     unpack_example_block_device, _EX_FIELDS, _GAMES, _SIZES)
+    g = torch.Generator().manual_seed(3)
+    R, B, T, na = 2, 7, 64, 65
+    ln = torch.randint(1, T, (R, B), generator=g, dtype=torch.int32)
+    ln[1, ::2] = -1  # unfinished games
+    arr = {"own": torch.randint(-2**62, 2**62, (R, B, T), generator=g, dtype=torch.int64),
+           "opp": torch.randint(0, 2**62, (R, B, T), generator=g, dtype=torch.int64), "pi": torch.rand((R, B, T, na), generator=g),
+           "z": torch.randint(-1, 2, (R, B, T), generator=g).to(torch.int8), "mover": torch.ones((R, B, T), dtype=torch.int8),
+           "act": torch.randint(0, 64, (R, B, T), generator=g).to(torch.uint8), "len": ln,
+           "winner": torch.zeros((R, B), dtype=torch.int8)}
+    block = build_example_block(arr, 1000, 50, "reversi")
+    offs, off = [], 0
+    for name, dt, esz in _EX_FIELDS:
+        offs.append(off)
+        off += (arr[name].numel() * esz + 255) & ~255
+    geom = {"B": B, "rounds": R, "t_max": T, "na": na, "game": _GAMES["reversi"], "size": 8, "offs": offs,
+            "ex_bytes": int(block.numel())}
+    dev = unpack_example_block_device(block, geom)
+    host = unpack_example_block(block)
+    got = dev.cpu()
+    for f in ("own", "opp", "z", "mover", "act", "game", "ply"):
+        assert np.array_equal(getattr(got, f), getattr(host, f)), f
+    assert np.array_equal(got.pi.view(np.uint32), host.pi.view(np.uint32)) and got.size == host.size == 8
+    assert len(dev) == int(ln.clamp(min=0).sum())
+    rt = DeviceExamples.from_host(host, "cpu")   # host -> device form -> host is the identity; concat keeps the order
+    both = concat_device_examples([rt, dev]).cpu()
+    assert np.array_equal(both.own, np.concatenate([host.own, host.own])) and np.array_equal(both.states()[:len(host)], host.states())
+    assert np.array_equal(dev.states().numpy(), host.states())
