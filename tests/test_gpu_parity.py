@@ -14,6 +14,7 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
@@ -850,6 +851,41 @@ def test_cfg3_800_sims_tree_geometry_vs_oracle_bitexact():
     assert cnt["n_sims"] == 2 * B * sims
 
 
+@pytest.mark.parametrize("stepwise", [True, False], ids=["step_kernels", "fused"])
+def test_deep_narrow_trees_vs_oracle_bitexact(stepwise):
+    """walks deeper than the lane group is wide: with c_puct = 0.05 the search exploits (mean 12 nodes per walk, many
+    walks beyond 16 levels), so the path's entries past the 16 that live in registers, the backup's loop over them and the
+    second and third chunk of wide nodes are all on the road.  Root N / W / P and every work counter vs the oracle, for
+    the step kernels (k_tree_step, hash evaluator through the step API) and the fused search."""
+    own, opp = _positions(40, seed=31)
+    own[:8], opp[:8] = 0x0000000810000000, 0x0000001008000000   # the start position: the deepest trees (mean 12 nodes per walk)
+    tm = np.where(np.arange(40) % 2 == 0, 1, -1).astype(np.int8)
+    sims, c = 400, 0.05
+    eng = _engine("reversi", 40, sims, "hash", c_puct=c)
+    eng.set_roots(own, opp, tm)
+    eng.reset_counters()
+    if stepwise:
+        eng.root_begin(); eng.evaluate(); eng.expand_backup()
+        for s_ in range(sims):
+            eng.select(s_); eng.evaluate(); eng.expand_backup()
+    else:
+        eng.search()
+    N, W, P = eng.root_stats()
+    eng.status()
+    tot, deepest = {}, 0.0
+    for g in range(40):
+        n, w, p, cnt = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(tm[g]), sims, orc.EVAL_HASH, c_puct=c)
+        deepest = max(deepest, cnt["n_path_nodes"] / cnt["n_sims"])
+        assert np.array_equal(N[g], n), g
+        assert np.array_equal(W[g].view(np.uint32), w.view(np.uint32)) and np.array_equal(P[g].view(np.uint32), p.view(np.uint32)), g
+        for k, v in cnt.items():
+            tot[k] = tot.get(k, 0) + v
+    got = eng.counters()
+    for k in ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded", "n_child_written", "n_env_steps"):
+        assert got[k] == tot[k], (k, got[k], tot[k])
+    assert deepest > 11  # the trees really are deep: a MEAN of 12 nodes per walk puts many walks beyond 16 levels
+
+
 def _legal_per_oracle(own, opp, act):
     return all(orc.reversi_legal(int(o), int(p)) >> int(a) & 1 for o, p, a in zip(own, opp, act))
 
@@ -1420,6 +1456,36 @@ def test_gather_examples_over_rccl_world_size_1():
         dist.destroy_process_group()
         for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             os.environ.pop(k, None)
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
+    """`python bench.py --gpus 2` for real -- two rank processes with real engines, the timed region, the ONE all-gather
+    of the example blocks, max-over-ranks timing and the per-rank proof -- as far as one GPU allows: the ranks share the
+    card over gloo (BZ_DIST_BACKEND=gloo; under nccl the same command is refused for want of a second device, which is
+    asserted too).  Small settings: 256 games per rank, 32 simulations."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--games", "256", "--sims", "32", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, env=dict(env, BZ_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    rk = out["ranks"]
+    assert rk["backend"] == "gloo" and rk["world_size"] == 2 and rk["distinct_devices"] == 1
+    assert [p["rank"] for p in rk["per_rank"]] == [0, 1] and len({p["pid"] for p in rk["per_rank"]}) == 2
+    assert all(p["device_uuid"] and p["games_finished"] >= 0 and p["seconds"] > 0 for p in rk["per_rank"])
+    assert abs(sum(p["games_finished"] for p in rk["per_rank"]) / max(p["seconds"] for p in rk["per_rank"]) - out["value"]) \
+        <= 0.02 * out["value"] + 1e-9  # value = all ranks' games / the slowest rank's time
+    assert "bytes received per rank" in out["config"]["parallelism"]
+    if torch.cuda.device_count() < 2:  # RCCL needs one device per rank: a clear refusal, not a crash inside init
+        r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r2.returncode != 0 and "GPU(s) visible" in (r2.stderr + r2.stdout)
 
 
 def test_net_evaluators_serve_the_small_reversi_boards():
