@@ -171,9 +171,16 @@ __device__ __forceinline__ void cnt_flush(const EngineDev& E, Cnt& c) {
 #pragma unroll
     for (int k = 0; k < CNT_N; ++k) {
         u32 x = c.v[k];
+        if (kGW >= 16) {  // few leads (lanes 0, kGW, ...): read them straight into scalar registers -- no LDS round trips
+            u32 sum = 0;
 #pragma unroll
-        for (int o = 32; o >= kGW; o >>= 1) x += __shfl_xor(x, o, 64);  // (lanes that are not leads hold zeros)
-        x = (u32)__builtin_amdgcn_readfirstlane((int)x);                 // lane 0 is a lead: it holds the wave's sum
+            for (int l = 0; l < 64; l += kGW) sum += (u32)__builtin_amdgcn_readlane((int)x, l);
+            x = sum;
+        } else {
+#pragma unroll
+            for (int o = 32; o >= kGW; o >>= 1) x += __shfl_xor(x, o, 64);  // (lanes that are not leads hold zeros)
+            x = (u32)__builtin_amdgcn_readfirstlane((int)x);                 // lane 0 is a lead: it holds the wave's sum
+        }
         mine = lane == k ? x : mine;
     }
     if (lane < CNT_N && mine && wave < (u32)E.n_cnt_slots)
