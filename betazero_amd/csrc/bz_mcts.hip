@@ -67,18 +67,27 @@ enum { ERR_EDGE_OVERFLOW = 1, ERR_TERMINAL_ROOT = 2, ERR_EXAMPLE_OVERFLOW = 4, E
 
 struct __attribute__((aligned(16))) PathEnt { u32 eidx; u32 w0; float W; u32 pad; };
 
+// the tree step's per-game words in ONE 64-byte line (they were nine arrays: nine cache lines, nine TLB lookups per game at
+// the head of every launch, all of them missing the L2 after the net kernel has streamed its weights through it)
+struct __attribute__((aligned(64))) GameHot {
+    u64 leaf_legal; u32 leaf_node, leaf_info;   // the leaf awaiting expansion / backup: its legal mask, node id, header
+    u32 depth, n_nodes, n_edges, leaf_slot;     // its depth; the tree's fill; the evaluator row of the leaf
+    u32 root_n, root_base, pad[6];              // the root's child count; visits a kept subtree came with (subtree reuse)
+};
+static_assert(sizeof(GameHot) == 64, "layout");
+
 struct EngineDev {
     int B, ncap, ecap, sims, na, t_max, rounds, temp_moves, openings, maxd, stagger;
     int compact;  // net evaluators: leaves needing evaluation are packed (c_own/c_opp/logits/value by slot)
     int reuse;    // BZ_ENGINE_REUSE_SUBTREE: two tree arenas; nodes/edges = this move's, *_alt = the previous move's
-    Node* nodes_alt; Edge* edges_alt; u32 *g_reuse, *g_root_base;
+    Node* nodes_alt; Edge* edges_alt; u32* g_reuse;
     float c_puct, dir_alpha, dir_eps;  // dir_eps > 0: Dirichlet noise on the root priors
     u64 seed, id_base, id_stride;
     Node* nodes; Edge* edges;
     u64 *g_own, *g_opp; int8_t* g_to_move; uint8_t* g_state; int32_t *g_moves, *g_nex, *g_round, *g_passes;
-    u32 *n_nodes, *n_edges, *depth, *leaf_node, *leaf_info, *root_n;
-    PathEnt* path;  // [B][maxd], game-major
-    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp, *leaf_legal, *c_own, *c_opp; u32* leaf_slot;
+    struct GameHot* hot;  // [B]
+    PathEnt* path;        // [B][maxd], game-major
+    uint8_t* leaf_kind; u64 *leaf_own, *leaf_opp, *c_own, *c_opp;
     float *logits, *value;
     u64 *ex_own, *ex_opp; float* ex_pi; int8_t *ex_z, *ex_mover; uint8_t* ex_act; int32_t* ex_len; int8_t* ex_winner;
     u32* root_N; float *root_W, *root_P;
@@ -519,7 +528,7 @@ __device__ __forceinline__ bool dev_root_init(const EngineDev& E, int g) {
     }
     Node r; r.own = own; r.opp = opp; r.legal = lg; r.edge0 = 0; r.info = (tm == 1 ? 1u : 0u) << 11;
     E.nodes[(size_t)g * E.ncap] = r;
-    E.leaf_legal[g] = lg; E.leaf_info[g] = r.info;  // what the expansion of this "leaf" reads
+    E.hot[g].leaf_legal = lg; E.hot[g].leaf_info = r.info;  // what the expansion of this "leaf" reads
     return true;
 }
 
@@ -543,7 +552,8 @@ __device__ __forceinline__ void dev_start_game(const EngineDev& E, int g, int ro
     }
     E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm;
     E.g_moves[g] = made; E.g_nex[g] = 0; E.g_round[g] = round; E.g_passes[g] = 0; E.g_state[g] = 0;
-    if (E.reuse) { E.g_reuse[g] = 0; E.g_root_base[g] = 0; }
+    if (E.reuse) E.g_reuse[g] = 0;
+    E.hot[g].root_base = 0;
 }
 
 template <class G>
@@ -582,7 +592,8 @@ __global__ void __launch_bounds__(256) k_set_roots(EngineDev E, const u64* own, 
     if (g >= E.B) return;
     E.g_own[g] = own[g]; E.g_opp[g] = opp[g]; E.g_to_move[g] = tm[g];
     E.g_state[g] = tm[g] == 0 ? 1 : 0;  // to_move 0 = slot not in use (the arena searches a subset of its games)
-    if (E.reuse) { E.g_reuse[g] = 0; E.g_root_base[g] = 0; }
+    if (E.reuse) E.g_reuse[g] = 0;
+    E.hot[g].root_base = 0;
     E.g_moves[g] = 0; E.g_nex[g] = 0; E.g_round[g] = 0; E.g_passes[g] = 0;
     if (g == 0) { E.flags[FLAG_ERR] = 0; E.flags[FLAG_FINISHED] = 0; E.flags[FLAG_NEVAL] = 0; E.flags[FLAG_NEVAL + 1] = 0; }
 }
@@ -602,7 +613,7 @@ __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_ro
     // nodes are laid out in breadth-first order and so are their edge blocks: the first edge of the node that gets
     // id k is the number of edges of all nodes before it, known the moment k is handed out
     u32 e_next = dn[0].info & 0xFFu;
-    E.root_n[g] = e_next;
+    E.hot[g].root_n = e_next;
     for (u32 i = 0; i < n_dst; ++i) {
         Node nd = dn[i];  // edge0 still points into the source arena
         if (nd.info & kTerm) continue;
@@ -622,7 +633,7 @@ __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_ro
         dn[i].edge0 = e_dst;
         e_dst += n;
     }
-    E.n_nodes[g] = n_dst; E.n_edges[g] = e_dst;
+    E.hot[g].n_nodes = n_dst; E.hot[g].n_edges = e_dst;
 }
 
 template <class G>
@@ -634,17 +645,17 @@ __global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
     if (keep) {
         dev_reroot<G>(E, g, keep);
         kind = LEAF_READY;
-        E.leaf_node[g] = 0; E.depth[g] = 0;
+        E.hot[g].leaf_node = 0; E.hot[g].depth = 0;
     } else if (E.g_state[g] == 0 && dev_root_init<G>(E, g)) {
         kind = LEAF_EVAL;
-        E.n_nodes[g] = 1; E.n_edges[g] = 0; E.leaf_node[g] = 0; E.depth[g] = 0;
-        if (E.reuse) E.g_root_base[g] = 0;
+        E.hot[g].n_nodes = 1; E.hot[g].n_edges = 0; E.hot[g].leaf_node = 0; E.hot[g].depth = 0;
+        E.hot[g].root_base = 0;
     }
     E.leaf_own[g] = E.g_own[g]; E.leaf_opp[g] = E.g_opp[g];
     E.leaf_kind[g] = kind;
     if (E.compact && kind == LEAF_EVAL) {
         u32 slot = atomicAdd(&E.flags[FLAG_NEVAL + 1], 1u);
-        E.leaf_slot[g] = slot; E.c_own[slot] = E.g_own[g]; E.c_opp[slot] = E.g_opp[g];
+        E.hot[g].leaf_slot = slot; E.c_own[slot] = E.g_own[g]; E.c_opp[slot] = E.g_opp[g];
     }
     if (g == 0) E.flags[FLAG_NEVAL] = 0;
 }
@@ -709,12 +720,11 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
         PathEnt* path = E.path + (size_t)g * E.maxd;
         // ---- round trip 1: every per-game word this step can need + the first kGW path entries, all independent
         int kind = E.leaf_kind[g], state = E.g_state[g];
-        u32 leaf = E.leaf_node[g], ninfo = E.leaf_info[g], ne = E.n_edges[g], nn = E.n_nodes[g], row = (u32)g;
-        if (E.compact) row = E.leaf_slot[g];
-        int depth0 = (int)E.depth[g], root_n = (int)E.root_n[g], rtm = E.g_to_move[g];
-        u64 nlegal = E.leaf_legal[g], rown = E.g_own[g], ropp = E.g_opp[g];
-        u32 root_base = 0;
-        if (E.reuse) root_base = E.g_root_base[g];
+        const GameHot hot = E.hot[g];
+        u32 leaf = hot.leaf_node, ninfo = hot.leaf_info, ne = hot.n_edges, nn = hot.n_nodes, row = E.compact ? hot.leaf_slot : (u32)g;
+        int depth0 = (int)hot.depth, root_n = (int)hot.root_n, rtm = E.g_to_move[g];
+        u64 nlegal = hot.leaf_legal, rown = E.g_own[g], ropp = E.g_opp[g];
+        u32 root_base = E.reuse ? hot.root_base : 0u;
         PathEnt pe0 = path[sub];  // (maxd >= kGW for every game)
         // the walk's first load too: root edges 0..kGW-1 (the root's edges start at index 0; whatever this step's
         // backup / expansion changes in them is patched in registers below) -- their latency hides behind the
@@ -735,7 +745,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 v = E.value[row];
                 if (sub == 0 && !(v >= -3.0e38f && v <= 3.0e38f)) atomicOr(&E.flags[FLAG_ERR], ERR_EVAL_NONFINITE);
                 n = dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c, st);
-                if (sub == 0) { E.n_edges[g] = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.root_n[g] = (u32)n; }
+                if (sub == 0) { E.hot[g].n_edges = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.hot[g].root_n = (u32)n; }
                 if (leaf == 0) { root_n = n; pre_ok = false; }  // the root's edges did not exist when re0 was fetched
             } else {
                 v = (float)((int)((ninfo >> 9) & 3u) - 1);
@@ -769,12 +779,12 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 dev_select<G>(E, g, sub, root, nn, leaf2, k2, depth, tv, c, sink, lpos, st);  // ---- one round trip per level
                 sink.flush(sub, depth);
                 if (sub == 0) {
-                    E.n_nodes[g] = nn; E.leaf_node[g] = leaf2; E.depth[g] = (u32)depth;
+                    E.hot[g].n_nodes = nn; E.hot[g].leaf_node = leaf2; E.hot[g].depth = (u32)depth;
                     if (k2 == LEAF_EVAL) {  // only an evaluated leaf's position is consumed (evaluator input)
-                        E.leaf_own[g] = lpos.own; E.leaf_opp[g] = lpos.opp; E.leaf_legal[g] = lpos.legal; E.leaf_info[g] = lpos.info;
+                        E.leaf_own[g] = lpos.own; E.leaf_opp[g] = lpos.opp; E.hot[g].leaf_legal = lpos.legal; E.hot[g].leaf_info = lpos.info;
                         if (E.compact) { want_slot = true; my_rank = atomicAdd(&s_need, 1u); slot_own = lpos.own; slot_opp = lpos.opp; }
                     } else {  // terminal leaf (new or revisited): the backup needs its value only
-                        E.leaf_info[g] = (u32)((int)tv + 1) << 9;
+                        E.hot[g].leaf_info = (u32)((int)tv + 1) << 9;
                     }
                 }
                 kind8 = (uint8_t)k2;
@@ -791,7 +801,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
         __syncthreads();
         if (want_slot) {
             const u32 slot = s_base + my_rank;
-            E.leaf_slot[g] = slot; E.c_own[slot] = slot_own; E.c_opp[slot] = slot_opp;
+            E.hot[g].leaf_slot = slot; E.c_own[slot] = slot_own; E.c_opp[slot] = slot_opp;
         }
     }
     st.mark(5);
@@ -828,7 +838,7 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
             group_fence();
             Stamps st; st.start();
             root.n = dev_expand<G>(E, g, sub, 0, G::legal(root.own, root.opp), (root.tm == 1 ? 1u : 0u) << 11, ls, ne, c, st);
-            if (sub == 0) E.root_n[g] = (u32)root.n;
+            if (sub == 0) E.hot[g].root_n = (u32)root.n;
             PathLds sink{mypath};
             for (int s = 0; s < E.sims; ++s) {
                 group_fence();  // this group's stores -> its loads
@@ -845,7 +855,7 @@ __global__ void __launch_bounds__(256) k_search_fused(EngineDev E, int eval_kind
                 group_fence();  // LDS path entries (lane 0) -> the lanes that back them up
                 dev_backup<G::GW>(E, g, sub, depth, v, mypath, leaf, e0, n, c);
             }
-            if (sub == 0) { E.n_nodes[g] = nn; E.n_edges[g] = ne; }
+            if (sub == 0) { E.hot[g].n_nodes = nn; E.hot[g].n_edges = ne; }
         }
     }
     cnt_flush<G::GW>(E, c);
@@ -1020,7 +1030,7 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                 const int i = sub + kGW * k;
                 if (i < rn) { Edge e = re[k]; e.w0 = e.w0 | (((e.w3 >> 24) & 0xFu) << kActShift); e.w3 = e.w3 & 0xFFu; edges[i] = e; }
             }
-            if (lead) { E.n_nodes[g] = nn; E.n_edges[g] = ne; E.root_n[g] = (u32)rn; }
+            if (lead) { E.hot[g].n_nodes = nn; E.hot[g].n_edges = ne; E.hot[g].root_n = (u32)rn; }
         }
     }
     cnt_flush<kGW>(E, c);
@@ -1108,7 +1118,7 @@ __global__ void __launch_bounds__(256) k_play(EngineDev E, int restart) {
     if (E.reuse) {  // keep the subtree iff it exists and the next search cannot outgrow the arena
         const bool ok = keep_node != 0 && keep_N + (u32)E.sims + 2u <= (u32)E.ncap;
         E.g_reuse[g] = ok ? keep_node : 0u;
-        E.g_root_base[g] = ok ? keep_N - 1u : 0u;
+        E.hot[g].root_base = ok ? keep_N - 1u : 0u;
     }
     E.g_own[g] = own; E.g_opp[g] = opp; E.g_to_move[g] = (int8_t)tm; E.g_moves[g] = made; E.g_nex[g] = nex;
 }
@@ -1141,8 +1151,8 @@ struct Carver {
 };
 
 struct Offsets {
-    int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_root_base, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, n_nodes, n_edges,
-        path, depth, leaf_node, leaf_info, root_n, leaf_kind, leaf_own, leaf_opp, leaf_legal, c_own, c_opp, leaf_slot, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
+    int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, hot,
+        path, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
         ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, total;
     int n_cnt_slots;
     int ncap, ecap, na, maxd;
@@ -1178,14 +1188,13 @@ Offsets carve(const bz_engine_cfg& c) {
     o.edges = k.take(B * o.ecap * (int64_t)sizeof(Edge));
     o.nodes_alt = k.take(reuse ? B * o.ncap * (int64_t)sizeof(Node) : 0);
     o.edges_alt = k.take(reuse ? B * o.ecap * (int64_t)sizeof(Edge) : 0);
-    o.g_reuse = k.take(reuse ? B * 4 : 0); o.g_root_base = k.take(reuse ? B * 4 : 0);
+    o.g_reuse = k.take(reuse ? B * 4 : 0);
     o.g_own = k.take(B * 8); o.g_opp = k.take(B * 8); o.g_to_move = k.take(B); o.g_state = k.take(B);
     o.g_moves = k.take(B * 4); o.g_nex = k.take(B * 4); o.g_round = k.take(B * 4); o.g_passes = k.take(B * 4);
-    o.n_nodes = k.take(B * 4); o.n_edges = k.take(B * 4);
-    o.path = k.take((int64_t)o.maxd * B * (int64_t)sizeof(PathEnt)); o.depth = k.take(B * 4); o.leaf_node = k.take(B * 4);
-    o.leaf_info = k.take(B * 4); o.root_n = k.take(B * 4);
-    o.leaf_kind = k.take(B); o.leaf_own = k.take(B * 8); o.leaf_opp = k.take(B * 8); o.leaf_legal = k.take(B * 8);
-    o.c_own = k.take(B * 8); o.c_opp = k.take(B * 8); o.leaf_slot = k.take(B * 4);
+    o.hot = k.take(B * (int64_t)sizeof(GameHot));
+    o.path = k.take((int64_t)o.maxd * B * (int64_t)sizeof(PathEnt));
+    o.leaf_kind = k.take(B); o.leaf_own = k.take(B * 8); o.leaf_opp = k.take(B * 8);
+    o.c_own = k.take(B * 8); o.c_opp = k.take(B * 8);
     o.logits = k.take(B * o.na * 4); o.value = k.take(B * 4);
     o.ex_own = k.take(R * B * T * 8); o.ex_opp = k.take(R * B * T * 8); o.ex_pi = k.take(R * B * T * o.na * 4);
     o.ex_z = k.take(R * B * T); o.ex_mover = k.take(R * B * T); o.ex_act = k.take(R * B * T);
@@ -1251,15 +1260,14 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.nodes = at<Node>(ws, o.nodes); d.edges = at<Edge>(ws, o.edges);
     d.reuse = (cfg->flags & BZ_ENGINE_REUSE_SUBTREE) ? 1 : 0;
     d.nodes_alt = at<Node>(ws, o.nodes_alt); d.edges_alt = at<Edge>(ws, o.edges_alt);
-    d.g_reuse = at<u32>(ws, o.g_reuse); d.g_root_base = at<u32>(ws, o.g_root_base);
+    d.g_reuse = at<u32>(ws, o.g_reuse);
     d.g_own = at<u64>(ws, o.g_own); d.g_opp = at<u64>(ws, o.g_opp); d.g_to_move = at<int8_t>(ws, o.g_to_move);
     d.g_state = at<uint8_t>(ws, o.g_state); d.g_moves = at<int32_t>(ws, o.g_moves); d.g_nex = at<int32_t>(ws, o.g_nex);
     d.g_round = at<int32_t>(ws, o.g_round); d.g_passes = at<int32_t>(ws, o.g_passes);
-    d.n_nodes = at<u32>(ws, o.n_nodes); d.n_edges = at<u32>(ws, o.n_edges); d.path = at<PathEnt>(ws, o.path);
-    d.depth = at<u32>(ws, o.depth); d.leaf_node = at<u32>(ws, o.leaf_node); d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
-    d.leaf_info = at<u32>(ws, o.leaf_info); d.root_n = at<u32>(ws, o.root_n);
-    d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp); d.leaf_legal = at<u64>(ws, o.leaf_legal);
-    d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp); d.leaf_slot = at<u32>(ws, o.leaf_slot);
+    d.hot = at<GameHot>(ws, o.hot); d.path = at<PathEnt>(ws, o.path);
+    d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
+    d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
+    d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp);
     d.compact = (cfg->eval_kind == BZ_EVAL_NET_F32 || cfg->eval_kind == BZ_EVAL_NET_BF16 ||
                  cfg->eval_kind == BZ_EVAL_NET_FP8) ? 1 : 0;
     d.logits = at<float>(ws, o.logits); d.value = at<float>(ws, o.value);
