@@ -289,6 +289,17 @@ template <int C_, int P_ = 512 / C_> struct Tw {
 #if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
+// weight-fragment loads of the bf16 tower.  Diagnostic option BZ_EXP_WEIGHTS_NT: non-temporal loads, to see whether the
+// 3.5 MB of fragments can pass through each XCD's 4-MB L2 without evicting the tree that the next tree step walks
+#ifdef BZ_EXP_WEIGHTS_NT
+#ifndef BZ_EXPERIMENT
+#error "BZ_EXP_WEIGHTS_NT is a diagnostic variant: build it through betazero_amd.build.build_variant()"
+#endif
+typedef unsigned bz_u32x4 __attribute__((ext_vector_type(4)));
+#define BZ_WLOAD(p) __builtin_nontemporal_load(reinterpret_cast<const bz_u32x4*>(p))
+#else
+#define BZ_WLOAD(p) (*(p))
+#endif
 #ifdef BZ_EXP_STAMPS
 __device__ unsigned long long g_dbg[8 * 4096];
 #define BZ_STAMP(var) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); var = _t; } while (0)
@@ -373,7 +384,7 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::NU], WSets<G>
 #pragma unroll
     for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(kc * G::MT + mt) * 64 + (unsigned)(32 * h + r)]);
+        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kc * G::MT + mt) * 64 + (unsigned)(32 * h + r)]));
     ap += G::KS * G::MT * 64;
     static_assert(G::ROWT, "compile-time taps are for row-tile units");
     int boff_n[2] = {boff[0], boff[1]};
@@ -422,7 +433,7 @@ __device__ __forceinline__ void chunk_step_pm(f32x16 (&acc)[G::MW][G::NU], WSets
 #pragma unroll
     for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, ap[(kc * G::MT + mt) * 64 + (unsigned)(32 * h + r)]);
+        for (int mt = 0; mt < G::MW; ++mt) nxt[kc][mt] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kc * G::MT + mt) * 64 + (unsigned)(32 * h + r)]));
     ap += G::KS * G::MT * 64;
     int boff_n[2];
     tap_off_pm<G>(tap_n, r, h, boff_n);
@@ -675,7 +686,7 @@ k_tower_bf16(TowerArgs T) {
 #pragma unroll
         for (int kc = 0; kc < G::KS; ++kc)
 #pragma unroll
-            for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, ap[(kc * G::MT + mt) * 64 + (unsigned)lane]);
+            for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kc * G::MT + mt) * 64 + (unsigned)lane]));
         ap += G::KS * G::MT * 64;
     }
 
