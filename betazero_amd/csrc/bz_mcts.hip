@@ -12,7 +12,8 @@
 // edge load, off the chain).  The select path is stored game-major as {edge index, w0, W} as seen at
 // selection time, so the backup of the next launch is one coalesced load + one 8-byte store per edge (nothing
 // else touches a game's tree in between), and the created leaf's legal mask / header go to per-game words, so
-// the expansion does not re-read the node.  Per-game scalars are SoA across games.  A simulation is two
+// the expansion does not re-read the node.  The words the tree step reads about a game sit in one 64-byte record
+// (GameHot); the caller-visible per-game arrays (positions, state, leaf buffers) are SoA across games.  A simulation is two
 // launches: k_tree_step ([expand + backup of the previous leaf] + [select of the next one]) and the evaluator;
 // leaves that need the net are packed through a double-buffered device-side counter.
 // Synthetic evaluators run the whole search in one launch (k_search_fused; k_search_fused_ttt for tic-tac-toe at
