@@ -51,3 +51,28 @@ def test_product_path_fails_loudly_without_gpu():
     with pytest.raises(RuntimeError, match="no HIP device"):
         import betazero_amd as bz
         bz.MCTSPlayer(1, sims=8).get_move(bz.TicTacToeBoard())
+
+
+def test_engine_config_limits_are_refused_with_a_reason():
+    """the tree's packed edge record holds node ids in 13 bits: sims <= BZ_ENGINE_MAX_SIMS (8189), <= 2045 with subtree
+    reuse; the tic-tac-toe lane knob takes -1, 0, 1, 2, 4, 8.  Out-of-range values come back as -1 / BZ_EINVAL with a
+    message that names the limit -- not as a silently corrupted tree."""
+    L = _lib.lib()
+
+    def ws(sims, flags=0, lanes=0, game=1):
+        cfg = _lib.EngineCfg(game, 4, sims, 0, 1.5, 0, 0, 1, 64, 0, 0, 0, 4, flags, 0.0, 0.0, lanes)
+        return L.bz_engine_workspace_bytes(C.byref(cfg))
+    hdr = open(os.path.join(ROOT, "include", "bz_abi.h")).read()
+    assert "#define BZ_ENGINE_MAX_SIMS 8189" in hdr and "#define BZ_ENGINE_MAX_SIMS_REUSE 2045" in hdr
+    assert ws(8189) > 0 and ws(8190) == -1 and b"8189" in L.bz_last_error()
+    assert ws(2045, _lib.ENGINE_REUSE_SUBTREE) > 0 and ws(2046, _lib.ENGINE_REUSE_SUBTREE) == -1
+    for lanes in (-1, 0, 1, 2, 4, 8):
+        assert ws(50, lanes=lanes, game=0) > 0
+    for lanes in (3, 16, -2):
+        assert ws(50, lanes=lanes, game=0) == -1
+    assert ws(0) == -1 and ws(800) > 0
+    # the workspace grows with sims as the layout says: nodes 32 B + 34 edges of 16 B per node (+ fixed per-game arrays)
+    def ws64(sims):  # 64 games: every array is then a multiple of the 256-byte carving granule
+        cfg = _lib.EngineCfg(1, 64, sims, 0, 1.5, 0, 0, 1, 64, 0, 0, 0, 64, 0, 0.0, 0.0, 0)
+        return L.bz_engine_workspace_bytes(C.byref(cfg))
+    assert (ws64(801) - ws64(800)) / 64 == 32 + 34 * 16
