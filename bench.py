@@ -764,8 +764,7 @@ def main():
                                  ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 3, 1)),
                                  # the steady-state figure's cross-check: ONE complete iteration, every game from its
                                  # opening to the last finished game, under the same clock
-                                 ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0)),
-                                 ("cfg1", cfg1_python_loop)):
+                                 ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0))):
                     try:
                         note(f"secondary {name}")
                         r = fn()
@@ -776,8 +775,18 @@ def main():
                         sec[name] = {"error": repr(e)}
                 out["secondary"] = sec
             if not args.no_cpu_baseline:
-                note("cpu baseline (oracle port on all cores, then the Python loop on one)")
+                note("cpu baseline (oracle port on all cores and on one thread, then the Python loops on one core)")
                 out["cpu_baseline"] = cpu_baseline_reversi(sims)
+                # BASELINE cfg 1 IS a CPU configuration: it belongs to the CPU-baseline leg (the only part of this file that
+                # may touch oracle/); `secondary.cfg1` carries the same object so that every config has its entry there
+                try:
+                    c1 = cfg1_python_loop()
+                    c1["kind"] = "cpu_baseline leg: build-authored Python MCTS (oracle/py_twin.py) over betazero_amd.TicTacToeBoard"
+                except Exception as e:
+                    c1 = {"error": repr(e)}
+                out["cpu_baseline"]["cfg1"] = c1
+                if "secondary" in out:
+                    out["secondary"]["cfg1"] = c1
                 note("cpu baseline done")
     if ctx.rank == 0:
         out["n_gpus"] = dist.get_world_size() if ctx.world > 1 else 1
