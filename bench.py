@@ -447,7 +447,7 @@ def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
             "vs_baseline": None, "data": "synthetic", "dtype": "u64+f32",
             "config": {"workload": f"ttt3x3_{B}games_{sims}sims_uniform_tree_only", "games_per_gpu": B,
                        "sims_per_move": sims, "step": "one complete self-play iteration of all games",
-                       "ttt_lanes": ttt_lanes if ttt_lanes else (2 if B >= 32768 else 4)},
+                       "ttt_lanes": ttt_lanes if ttt_lanes else 4},
             "roofline": {"bound": "hbm", "kernel": "k_search_fused<TicTacToe>", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tb / max(launches, 1)},

@@ -423,7 +423,10 @@ struct EdgeFmtTttFused { static __device__ __forceinline__ Edge make(float P, in
 // leaf's legal mask (known to the caller: the root's or the node select just created).
 // `info` = the leaf's header word as created (child count 0): the header is rewritten, never re-read.
 // Returns the number of edges written (they start at the old n_edges_g).
-template <class G, int kGW = G::GW, bool kHeader = true, class Fmt = EdgeFmtPacked>
+// kUniform: the caller's logits are all equal (the uniform evaluator, BASELINE cfg 2).  The spec's arithmetic then
+// collapses without changing a bit: m = 0, every e = expf_spec(0) = 1.0 exactly, their sequential sum is the integer n
+// exactly, P = 1 / float(n) by the same correctly rounded division -- no exponentials, no serial sum, no logits.
+template <class G, int kGW = G::GW, bool kHeader = true, class Fmt = EdgeFmtPacked, bool kUniform = false>
 __device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info,
                                           const LogitSrc& ls, u32& n_edges_g, Cnt& c, Stamps& st) {
     constexpr int kCH = (G::MAXCH + kGW - 1) / kGW;
@@ -443,24 +446,35 @@ __device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u3
         // this lane's moves: the sub-th, (sub+GW)-th, ... legal actions
         int a[kCH]; float x[kCH];
         float m = -__builtin_inff();
+        u32 rest = (u32)legal;  // small boards (tic-tac-toe: 9 cells): walk the mask instead of a rank search per move
+        if (G::NA <= 32)
+            for (int j = 0; j < sub; ++j) rest &= rest - 1u;
 #pragma unroll
         for (int k = 0; k < kCH; ++k) {
-            a[k] = (sub + kGW * k < n) ? nth_bit(legal, sub + kGW * k) : -1;
-            x[k] = a[k] >= 0 ? ls(a[k]) : -__builtin_inff();
-            m = x[k] > m ? x[k] : m;
+            if (G::NA <= 32) {  // this lane's k-th move = the lowest bit left; then skip the other lanes' kGW - 1 moves
+                a[k] = (sub + kGW * k < n && rest) ? (int)__builtin_ctz(rest) : -1;
+#pragma unroll
+                for (int j = 0; j < kGW; ++j) rest &= rest - 1u;
+            } else {
+                a[k] = (sub + kGW * k < n) ? nth_bit(legal, sub + kGW * k) : -1;
+            }
+            if (!kUniform) {
+                x[k] = a[k] >= 0 ? ls(a[k]) : -__builtin_inff();
+                m = x[k] > m ? x[k] : m;
+            }
         }
-        m = group_max<kGW>(m);
+        if (!kUniform) m = group_max<kGW>(m);
         st.mark(1);  // (the evaluator's row has arrived)
         float ex[kCH];
 #pragma unroll
-        for (int k = 0; k < kCH; ++k) ex[k] = a[k] >= 0 ? expf_spec(x[k] - m) : 0.0f;
+        for (int k = 0; k < kCH; ++k) ex[k] = a[k] >= 0 ? (kUniform ? 1.0f : expf_spec(x[k] - m)) : 0.0f;
         // ascending-action serial sum (the spec's order): the partial sum travels up the group one lane per step
         // (lane t adds its own term to what lane t-1 holds), every step one DPP add; lanes past the last move hold
         // +0.0, which leaves a positive sum unchanged, so the chain runs its full length without tests.
-        float s = 0.0f;
+        float s = kUniform ? (float)n : 0.0f;
 #pragma unroll
         for (int k = 0; k < kCH; ++k) {
-            if (kGW * k < n) {
+            if (!kUniform && kGW * k < n) {
                 float part = s + ex[k];  // (lane 0's is the true partial sum; the others are overwritten below)
 #pragma unroll
                 for (int t = 1; t < kGW; ++t) {
@@ -888,11 +902,19 @@ __device__ __forceinline__ float puct_score(const Edge& e, float c_puct, float s
     return q + u;
 }
 
-template <int kGW>
-__global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_kind) {
+// kUniform = the uniform evaluator (cfg 2) at compile time: the kernel is at ~90 % of its SIMDs' issue slots, so the
+// exponentials, the serial softmax sum and the position hash it does not need are time, not just instructions.
+template <int kGW, bool kUniform>
+__global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E) {
     using G = TicTacToe;
+    constexpr int eval_kind = kUniform ? BZ_EVAL_UNIFORM : BZ_EVAL_HASH;
     constexpr int kGPB = 256 / kGW, kCH = (G::MAXCH + kGW - 1) / kGW;
     __shared__ PathEntLds s_path[kGPB][G::MAXD];
+    // sqrt(max(visits, 1)) for every visit count this kernel can see (sims <= 120): the correctly rounded square root is
+    // ~20 instructions, the table one LDS read -- and holds the very values fsqrt() returns
+    __shared__ float s_sqrt[128];
+    if (threadIdx.x < 128) s_sqrt[threadIdx.x] = fsqrt((float)(threadIdx.x > 1 ? threadIdx.x : 1));
+    __syncthreads();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = t / kGW, sub = t % kGW;
     PathEntLds* mypath = s_path[threadIdx.x / kGW];
@@ -908,10 +930,10 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
             LogitSrc ls; ls.kind = eval_kind; ls.row = nullptr;
             const u64 rown = E.g_own[g], ropp = E.g_opp[g];
             const int rtm = E.g_to_move[g];
-            ls.h = hash_pos(rown, ropp);
+            ls.h = kUniform ? 0 : hash_pos(rown, ropp);
             group_fence();
             Stamps st; st.start();
-            dev_expand<G, kGW, true, EdgeFmtTttFused>(E, g, sub, 0, G::legal(rown, ropp), (rtm == 1 ? 1u : 0u) << 11, ls, ne, c, st);
+            dev_expand<G, kGW, true, EdgeFmtTttFused, kUniform>(E, g, sub, 0, G::legal(rown, ropp), (rtm == 1 ? 1u : 0u) << 11, ls, ne, c, st);
             group_fence();
             const int rn = (int)ne;  // the root's children (>= 1: a terminal root was refused above)
             Edge re[kCH];
@@ -930,22 +952,24 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
             for (int s = 0; s < E.sims; ++s) {
                 group_fence();  // this group's stores of the previous simulation -> its loads
                 // ---- level 0 from registers
-                float bests = -__builtin_inff(), bestW = 0.0f; int best = 0; u32 bestN = 0, bestca = 0;
+                // (first maximum = highest score, lowest child index on ties: every lane scans its own edges in ascending
+                // order, then ONE exchange across the group's lanes -- the order of the comparisons does not matter)
+                float bestW = 0.0f; int best = 0; u32 bestN = 0, bestca = 0;
                 {
-                    const float sq = fsqrt((float)(s > 1 ? s : 1));
+                    const float sq = s_sqrt[s];
+                    Cand lb; lb.sc = -__builtin_inff(); lb.i = sub; lb.w0 = 0; lb.w3 = 0; lb.W = 0.0f;
 #pragma unroll
                     for (int k = 0; k < kCH; ++k) {
-                        int i = sub + kGW * k;
-                        float sc = -__builtin_inff();
+                        const int i = sub + kGW * k;
                         if (i < rn) {  // puct_score with the cached terms
                             float u = rcp[k] * sq;
                             u = fdiv(u, 1.0f + (float)re[k].w0);
-                            sc = rq[k] + u;
+                            const float sc = rq[k] + u;
+                            if (sc > lb.sc) { lb.sc = sc; lb.i = i; lb.w0 = re[k].w0; lb.w3 = re[k].w3; lb.W = re[k].W; }
                         }
-                        Cand cd; cd.sc = sc; cd.i = i; cd.w0 = re[k].w0; cd.w3 = re[k].w3; cd.W = re[k].W;
-                        group_argmax<kGW>(cd);
-                        if (cd.sc > bests) { bests = cd.sc; best = cd.i; bestN = cd.w0; bestca = cd.w3; bestW = cd.W; }
                     }
+                    group_argmax<kGW>(lb);
+                    best = lb.i; bestN = lb.w0; bestca = lb.w3; bestW = lb.W;
                 }
                 if (lead) { c.v[CNT_SIMS]++; c.v[CNT_PATH_NODES]++; c.v[CNT_CHILD_SCORED] += (u32)rn; }
                 const int i0 = best; const u32 N0 = bestN; const float W0 = bestW;
@@ -964,16 +988,20 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                         if ((ca >> 28) & 1u) { v = (float)((int)((ca >> 29) & 3u) - 1); break; }  // terminal, revisited
                         const u32 e0 = (ca >> 8) & 0xFFFu; const int n = (int)((ca >> 20) & 0xFu);
                         const u32 sumN = parentN - 1u;  // visits of the child's edges = visits into it minus the creating one
-                        const float sq = fsqrt((float)(sumN > 1u ? sumN : 1u));
+                        const float sq = s_sqrt[sumN & 127u];
                         const Edge* ed = edges + e0;
-                        bests = -__builtin_inff(); best = 0; bestN = 0; bestca = 0; bestW = 0.0f;
+                        Cand lb; lb.sc = -__builtin_inff(); lb.i = sub; lb.w0 = 0; lb.w3 = 0; lb.W = 0.0f;
 #pragma unroll
                         for (int k = 0; k < kCH; ++k) {
-                            Cand cd; cd.i = sub + kGW * k; cd.sc = -__builtin_inff(); cd.W = 0.0f; cd.w0 = 0; cd.w3 = 0;
-                            if (cd.i < n) { Edge e = ed[cd.i]; cd.sc = puct_score(e, E.c_puct, sq); cd.w0 = e.w0; cd.w3 = e.w3; cd.W = e.W; }
-                            group_argmax<kGW>(cd);
-                            if (kGW * k < n && cd.sc > bests) { bests = cd.sc; best = cd.i; bestN = cd.w0; bestca = cd.w3; bestW = cd.W; }
+                            const int i = sub + kGW * k;
+                            if (i < n) {
+                                const Edge e = ed[i];
+                                const float sc = puct_score(e, E.c_puct, sq);
+                                if (sc > lb.sc) { lb.sc = sc; lb.i = i; lb.w0 = e.w0; lb.w3 = e.w3; lb.W = e.W; }
+                            }
                         }
+                        group_argmax<kGW>(lb);
+                        best = lb.i; bestN = lb.w0; bestca = lb.w3; bestW = lb.W;
                         pe_idx = e0 + (u32)best;
                         if (lead) {
                             c.v[CNT_CHILD_SCORED] += (u32)n;
@@ -994,9 +1022,9 @@ __global__ void __launch_bounds__(256) k_search_fused_ttt(EngineDev E, int eval_
                         new_ca = ttt_ca(id, 0, 0, (u32)act, true, tv);
                         v = (float)tv;
                     } else {
-                        ls.h = hash_pos(own, opp);
+                        ls.h = kUniform ? 0 : hash_pos(own, opp);
                         const u32 e0 = ne;
-                        dev_expand<G, kGW, false, EdgeFmtTttFused>(E, g, sub, id, lg, 0, ls, ne, c, st);
+                        dev_expand<G, kGW, false, EdgeFmtTttFused, kUniform>(E, g, sub, id, lg, 0, ls, ne, c, st);
                         new_ca = ttt_ca(id, e0, ne - e0, (u32)act, false, 0);
                         v = eval_kind == BZ_EVAL_HASH ? hash_value(ls.h) : 0.0f;
                     }
@@ -1250,9 +1278,10 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
     e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1;
-    // measured on MI355X at 65,536 games x 50 sims (profiles/r02_cfg2_*): 2 lanes 0.185 ms, 4 lanes 0.190 ms, 8 lanes
-    // 0.294 ms per launch; small batches keep 4 lanes so that the chip still sees a few waves per CU
-    e->ttt_gw = cfg->ttt_lanes > 0 ? cfg->ttt_lanes : (cfg->ttt_lanes < 0 ? 0 : (cfg->n_games >= 32768 ? 2 : 4));
+    // measured on MI355X at 65,536 games x 50 sims: round 2 (profiles/r02_bench_ttt_gw*) 2 lanes 0.185 ms, 4 lanes 0.190 ms,
+    // 8 lanes 0.294 ms per launch; round 3, after the kernel became issue-bound and lost a third of its instructions
+    // (profiles/r03_bench_ttt_lanes.txt): 1 lane 0.162, 2 lanes 0.137, 4 lanes 0.134, 8 lanes 0.181 ms -> 4 lanes
+    e->ttt_gw = cfg->ttt_lanes > 0 ? cfg->ttt_lanes : (cfg->ttt_lanes < 0 ? 0 : 4);
     EngineDev& d = e->dev;
     d.B = cfg->n_games; d.ncap = o.ncap; d.ecap = o.ecap; d.sims = cfg->sims; d.na = o.na; d.t_max = cfg->t_max;
     d.rounds = cfg->rounds; d.temp_moves = cfg->temp_moves; d.openings = cfg->openings; d.maxd = o.maxd;
@@ -1402,12 +1431,18 @@ BZ_EXPORT int32_t bz_engine_search(bz_engine* e, void* stream) {
         ProfScope ps(BZ_PROF_SEARCH_FUSED, stream);
         if (e->cfg.game == BZ_GAME_TTT && e->cfg.sims <= kTttFusedMaxSims && e->ttt_gw > 0) {
             const dim3 grid = grid_groups(e->dev.B, e->ttt_gw);
+#define BZ_TTT_FUSED(GWN)                                                                                              \
+    do {                                                                                                                \
+        if (ek == BZ_EVAL_UNIFORM) hipLaunchKernelGGL((k_search_fused_ttt<GWN, true>), grid, dim3(256), 0, (hipStream_t)stream, e->dev); \
+        else hipLaunchKernelGGL((k_search_fused_ttt<GWN, false>), grid, dim3(256), 0, (hipStream_t)stream, e->dev);     \
+    } while (0)
             switch (e->ttt_gw) {
-            case 1: hipLaunchKernelGGL(k_search_fused_ttt<1>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
-            case 2: hipLaunchKernelGGL(k_search_fused_ttt<2>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
-            case 8: hipLaunchKernelGGL(k_search_fused_ttt<8>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
-            default: hipLaunchKernelGGL(k_search_fused_ttt<4>, grid, dim3(256), 0, (hipStream_t)stream, e->dev, ek); break;
+            case 1: BZ_TTT_FUSED(1); break;
+            case 2: BZ_TTT_FUSED(2); break;
+            case 8: BZ_TTT_FUSED(8); break;
+            default: BZ_TTT_FUSED(4); break;
             }
+#undef BZ_TTT_FUSED
             BZ_LAUNCH_CHECK("k_search_fused_ttt");
             return BZ_OK;
         }

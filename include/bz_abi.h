@@ -209,7 +209,7 @@ typedef struct bz_engine_cfg {
     float dirichlet_eps;     /* > 0: root priors P' = (1 - eps) P + eps Dirichlet(alpha), a fresh draw per
                               * search keyed by (seed, game id, moves made) -- DESIGN.md 3.9 */
     int32_t ttt_lanes;       /* tic-tac-toe fused search (synthetic evaluators, sims <= 120): lanes that serve one game --
-                              * 0 = default (2 at >= 32,768 games, else 4), 1 / 2 / 4 / 8 = as given, -1 = the generic
+                              * 0 = default (4), 1 / 2 / 4 / 8 = as given, -1 = the generic
                               * any-game fused kernel.  Results are identical for every setting. */
 } bz_engine_cfg;
 /* The tree's edge record packs (visits 14 bits | action | the child's edge count, terminal flag and value) and

@@ -42,8 +42,9 @@ def test_tree_kernels_stay_within_their_register_budget(tmp_path):
     step = _find(res, "k_tree_step", "ReversiTILi8")          # cfg 3's tree step: 4+ waves per SIMD
     assert step["vgpr"] <= 96 and step["vspill"] == 0 and step["sspill"] == 0 and step["scratch"] == 0, step
     for gw, cap in (("ILi2E", 128), ("ILi4E", 128)):          # cfg 2's fused search (2 lanes per game is the default)
-        k = _find(res, "k_search_fused_ttt", gw)
-        assert k["vgpr"] <= cap and k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0, (gw, k)
+        for uni in ("Lb1E", "Lb0E"):                           # uniform evaluator (cfg 2) / hash evaluator
+            k = _find(res, "k_search_fused_ttt", gw + uni)
+            assert k["vgpr"] <= cap and k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0, (gw, uni, k)
     play = _find(res, "k_play", "ReversiTILi8")
     assert play["vspill"] == 0 and play["scratch"] == 0, play
 
