@@ -448,7 +448,8 @@ def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
             "config": {"workload": f"ttt3x3_{B}games_{sims}sims_uniform_tree_only", "games_per_gpu": B,
                        "sims_per_move": sims, "step": "one complete self-play iteration of all games",
                        "ttt_lanes": ttt_lanes if ttt_lanes else 4},
-            "roofline": {"bound": "hbm", "kernel": "k_search_fused<TicTacToe>", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_search_fused_ttt<%s, uniform>" % (ttt_lanes if ttt_lanes > 0 else 4) if ttt_lanes >= 0
+                         else "k_search_fused<TicTacToe> (generic)", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tb / max(launches, 1)},
             "sims_per_s": cnt["n_sims"] * ctx.world / dt, "counters": cnt}
