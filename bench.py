@@ -762,7 +762,7 @@ def main():
                                  ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
                                  ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3)),
                                  # cfg 5 as SURVEY 7 reads it: the fp8 net as the in-loop evaluator of 8192 concurrent games
-                                 ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 3, 1)),
+                                 ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 6, 2)),
                                  # the steady-state figure's cross-check: ONE complete iteration, every game from its
                                  # opening to the last finished game, under the same clock
                                  ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0))):
