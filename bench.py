@@ -455,6 +455,21 @@ def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
             "sims_per_s": cnt["n_sims"] * ctx.world / dt, "counters": cnt}
 
 
+_STREAMS = {}
+
+
+def pipeline_streams(dev, n):
+    """the pipelines' HIP streams, created ONCE per process and reused by every run in it.  torch hands out streams
+    round-robin from a pool, so a second run in the same process would get the pool's next pair -- and that pair is
+    measurably slower on this stack (tools/exp_repeat.py: six identical runs in one process read 166 / 147 / 167 / ... games/s:
+    only the run on the pool's second pair is slow, whatever it runs)."""
+    import torch
+    key = (str(dev), n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _STREAMS[key]
+
+
 def run_reversi(ctx, args, B, sims, K, W):
     import torch
     import torch.distributed as dist
@@ -476,7 +491,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     NS = max(1, args.streams)
     sizes = [B // NS + (1 if i < B % NS else 0) for i in range(NS)]
     Bs = sizes[0]
-    streams = [torch.cuda.Stream(device=ctx.dev) for _ in range(NS)]
+    streams = pipeline_streams(ctx.dev, NS)
     engs = [SelfPlayEngine("reversi", sizes[i], sims, "net_" + prec, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
                            game_id_base=ctx.rank * B + sum(sizes[:i]), game_id_stride=ctx.world * B, device=ctx.dev,
                            stagger=PLIES_PER_GAME if args.mode == "steady" else 0, reuse_subtree=args.reuse_subtree,
@@ -758,14 +773,15 @@ def main():
                 sec = {}
                 a_fp8 = argparse.Namespace(**{**vars(args), "precision": "fp8", "mode": "steady"})
                 a_iter = argparse.Namespace(**{**vars(args), "mode": "iteration"})
-                for name, fn in (("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
-                                 ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
-                                 ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3)),
-                                 # cfg 5 as SURVEY 7 reads it: the fp8 net as the in-loop evaluator of 8192 concurrent games
-                                 ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 6, 2)),
-                                 # the steady-state figure's cross-check: ONE complete iteration, every game from its
-                                 # opening to the last finished game, under the same clock
-                                 ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0))):
+                for name, fn in (
+                        # cfg 5 as SURVEY 7 reads it: the fp8 net as the in-loop evaluator of 8192 concurrent games
+                        ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 6, 2)),
+                        # the steady-state figure's cross-check: ONE complete iteration, every game from its
+                        # opening to the last finished game, under the same clock
+                        ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0)),
+                        ("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
+                        ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
+                        ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3))):
                     try:
                         note(f"secondary {name}")
                         r = fn()
