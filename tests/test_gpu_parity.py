@@ -1458,6 +1458,30 @@ def test_gather_examples_over_rccl_world_size_1():
             os.environ.pop(k, None)
 
 
+def test_examples_do_not_depend_on_how_the_games_are_sharded():
+    """rank r plays global ids r*B + i and the RNG is keyed by the global id, so the pooled examples of G ranks
+    are the examples one GPU would have produced for the same ids.  Two engines configured as the two ranks of a 2-GPU run
+    (game_id_base 0 / B, stride 2B) against ONE engine playing all 2B games (openings by id, tau = 1 sampling by id):
+    identical rows game by game -- with the synthetic evaluator and with the bf16 net in the loop."""
+    from betazero_amd.net import DeviceNet
+    B, sims = 24, 12
+    dn = DeviceNet.from_module(_net(64, 2, bf16=True), 2 * B)
+    for ev, net in (("hash", None), ("net_bf16", dn)):
+        whole = _engine("reversi", 2 * B, sims, ev, net=net, temp_moves=8, openings=1, seed=11, game_id_base=0, game_id_stride=2 * B)
+        halves = [_engine("reversi", B, sims, ev, net=net, temp_moves=8, openings=1, seed=11, game_id_base=r * B, game_id_stride=2 * B)
+                  for r in range(2)]
+        for e in [whole] + halves:
+            e.run_iteration()
+        a = whole.examples()
+        for r, h in enumerate(halves):
+            b = h.examples()
+            assert sorted(set(b.game)) == list(range(r * B, (r + 1) * B))
+            for gid in range(r * B, (r + 1) * B):
+                ma, mb = a.game == gid, b.game == gid
+                assert np.array_equal(a.own[ma], b.own[mb]) and np.array_equal(a.act[ma], b.act[mb]), (ev, gid)
+                assert np.array_equal(a.pi[ma].view(np.uint32), b.pi[mb].view(np.uint32)) and np.array_equal(a.z[ma], b.z[mb]), (ev, gid)
+
+
 def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     """`python bench.py --gpus 2` for real -- two rank processes with real engines, the timed region, the ONE all-gather
     of the example blocks, max-over-ranks timing and the per-rank proof -- as far as one GPU allows: the ranks share the
