@@ -92,6 +92,58 @@ def test_reversi_step_batch_arbitrary_positions_and_illegal_actions():
     assert np.array_equal(out.cpu().numpy().view(np.uint64), legal)
 
 
+def test_reversi_step_batch_100k_random_positions_every_output_vs_oracle():
+    """the batched env step on 100,003 random positions of every density (sparse openings to nearly full boards, where
+    passes, must-pass and terminal positions are common) with random actions -- legal moves, passes, occupied cells, moves
+    that flip nothing -- against the oracle's rules, all five outputs: stones after the move, next legal mask, status
+    (RUNNING / TERMINAL / ILLEGAL / MUST_PASS), winner.  (Round 3 rewrote this kernel: flips and east / west moves by carry
+    propagation, the rare second legal mask once per lane: the fixtures alone hold 1200 positions.)"""
+    rng = np.random.default_rng(2026)
+    n = 100003  # ragged: not a multiple of 4 games per lane
+    a = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64)
+    b = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64)
+    keep = np.full(n, ~np.uint64(0))
+    for _ in range(3):  # thin out a share of the boards: densities from ~6 % to 50 % per colour
+        m = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, n).astype(np.uint64)
+        keep = np.where(rng.random(n) < 0.4, keep & m, keep)
+    fill = rng.random(n) < 0.25  # and fill others up: nearly full boards
+    own, opp = a & ~b & keep, b & ~a & keep
+    extra = np.where(fill, ~(own | opp) & (rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)), np.uint64(0))
+    own = own | (extra & a)
+    opp = opp | (extra & ~a)
+    legal = np.array([orc.reversi_legal(int(o), int(p)) for o, p in zip(own, opp)], dtype=np.uint64)
+    act = rng.integers(0, 65, n).astype(np.uint8)
+    pick_legal = (rng.random(n) < 0.6) & (legal != 0)   # most actions legal, the rest anything (incl. pass)
+    low = np.array([(int(l) & -int(l)).bit_length() - 1 if l else 64 for l in legal], dtype=np.uint8)
+    act = np.where(pick_legal, low, act).astype(np.uint8)
+    act = np.where((legal == 0) & (rng.random(n) < 0.7), 64, act).astype(np.uint8)
+    on, pn, lg, st, w = _reversi_step(own, opp, act)
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    for i in range(n):
+        o, p, ac, l = int(own[i]), int(opp[i]), int(act[i]), int(legal[i])
+        ok = (l == 0) if ac == 64 else bool(l >> ac & 1)
+        if not ok:
+            assert st[i] == _lib.ST_ILLEGAL and (int(on[i]), int(pn[i]), int(lg[i]), int(w[i])) == (o, p, l, 0), i
+            seen[2] += 1
+            continue
+        no, np_ = (p, o) if ac == 64 else orc.reversi_apply(o, p, 8, ac >> 3, ac & 7)[:2][::-1]
+        # reversi_apply returns (mover's stones, opponent's stones) after the move; the kernel returns the NEXT mover's view
+        assert (int(on[i]), int(pn[i])) == (no, np_), i
+        nl = orc.reversi_legal(no, np_)
+        assert int(lg[i]) == nl, i
+        if nl == 0 and orc.reversi_legal(np_, no) == 0:
+            d = bin(np_).count("1") - bin(no).count("1")
+            assert st[i] == _lib.ST_TERMINAL and int(w[i]) == (d > 0) - (d < 0), i
+            seen[1] += 1
+        elif nl == 0:
+            assert st[i] == _lib.ST_MUST_PASS and w[i] == 0, i
+            seen[3] += 1
+        else:
+            assert st[i] == _lib.ST_RUNNING and w[i] == 0, i
+            seen[0] += 1
+    assert min(seen.values()) > 200, seen  # every status really occurs, many times
+
+
 def test_ttt_step_batch_exhaustive():
     d = np.load(os.path.join(G, "ttt_exhaustive.npz"))
     pos = np.concatenate([d["pos"], d["extra"]])
