@@ -938,6 +938,38 @@ def test_deep_narrow_trees_vs_oracle_bitexact(stepwise):
     assert deepest > 11  # the trees really are deep: a MEAN of 12 nodes per walk puts many walks beyond 16 levels
 
 
+@pytest.mark.parametrize("stepwise", [True, False], ids=["step_kernels", "fused"])
+def test_search_at_the_packed_edge_limit_vs_oracle_bitexact(stepwise):
+    """sims = BZ_ENGINE_MAX_SIMS = 8189: the tree then holds 8190 nodes -- every one of the 13 bits of a child id, visit
+    counts up to 8189 in the 14-bit field, edge offsets up to ~70 k -- and must still equal the oracle's tree bit for bit
+    (root N / W / P and the work counters); sims = 8190 is refused (tests/test_abi.py)."""
+    sims = 8189
+    own = np.array([0x0000000810000000, 0x0000001008000000], np.uint64)
+    opp = np.array([0x0000001008000000, 0x0000000810000000], np.uint64)
+    tm = np.array([1, -1], np.int8)
+    eng = _engine("reversi", 2, sims, "hash")
+    eng.set_roots(own, opp, tm)
+    eng.reset_counters()
+    if stepwise:
+        eng.root_begin(); eng.evaluate(); eng.expand_backup()
+        for s_ in range(sims):
+            eng.select(s_); eng.evaluate(); eng.expand_backup()
+    else:
+        eng.search()
+    N, W, P = eng.root_stats()
+    eng.status()
+    tot = {}
+    for g in range(2):
+        n, w, p, cnt = orc.mcts_search(orc.GAME_REVERSI, int(own[g]), int(opp[g]), int(tm[g]), sims, orc.EVAL_HASH)
+        assert N[g].sum() == sims and np.array_equal(N[g], n), g
+        assert np.array_equal(W[g].view(np.uint32), w.view(np.uint32)) and np.array_equal(P[g].view(np.uint32), p.view(np.uint32)), g
+        for k, v in cnt.items():
+            tot[k] = tot.get(k, 0) + v
+    got = eng.counters()
+    for k in ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded", "n_child_written", "n_env_steps"):
+        assert got[k] == tot[k], (k, got[k], tot[k])
+
+
 def _legal_per_oracle(own, opp, act):
     return all(orc.reversi_legal(int(o), int(p)) >> int(a) & 1 for o, p, a in zip(own, opp, act))
 
