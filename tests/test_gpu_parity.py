@@ -1406,6 +1406,33 @@ def test_arena_both_players_only_ever_play_legal_moves_stress():
         assert s["games"] == 2048 and s["wins"] + s["draws"] + s["losses"] == 2048
 
 
+def test_subtree_reuse_at_the_packed_edge_limit_vs_oracle_bitexact():
+    """sims = BZ_ENGINE_MAX_SIMS_REUSE = 2045 with subtree reuse: the arena holds 4 x 2047 = 8188 nodes, kept subtrees of
+    up to ~2000 nodes are copied and renumbered (child ids and first-edge offsets rewritten inside the packed edge words),
+    visit counts of kept roots exceed the fresh-search range.  The first three moves of four games, rows and counters
+    against the oracle."""
+    sims, n, moves = 2045, 4, 3
+    eng = _engine("reversi", n, sims, "hash", temp_moves=8, openings=1, seed=5, reuse_subtree=True)
+    eng.reset_games()
+    eng.reset_counters()
+    for _ in range(moves):
+        eng.search()
+        eng.play(False)
+    eng.status()
+    rows = _ex_rows(eng, moves)
+    exp = {}
+    for g in range(n):
+        r = orc.selfplay_game(orc.GAME_REVERSI, g, sims, orc.EVAL_HASH, 8, 1, 5, reuse=True, max_moves=moves)
+        assert np.array_equal(rows["own"][g].view(np.uint64), r["own"]) and np.array_equal(rows["act"][g], r["act"]), g
+        assert np.array_equal(rows["pi"][g].view(np.uint32), r["pi"].view(np.uint32)), g
+        for k, v in r["counters"].items():
+            exp[k] = exp.get(k, 0) + v
+    cnt = eng.counters()
+    for k in ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded", "n_child_written", "n_env_steps"):
+        assert cnt[k] == exp[k], (k, cnt[k], exp[k])
+    assert cnt["n_sims"] == n * moves * sims
+
+
 def test_subtree_reuse_selfplay_vs_oracle_bitexact():
     """subtree reuse: the chosen child's subtree is copied to the front of the other arena and searched on
     (`sims` new simulations on top of the retained statistics), through passes, with the arena-capacity rule, with and
