@@ -98,42 +98,48 @@ def launch_ranks(n, argv):
 
 
 def rehearsal(args, rank, world):
-    """CPU-only rehearsal of the N>1 plumbing (no GPU in this process, BZ_BENCH_REHEARSAL=1):
-    process group, barrier + max-over-ranks timing and the single all-gather on example blocks of
-    the engine's exact layout.  Measures nothing about the hot path and says so."""
+    """CPU-only rehearsal of the N>1 plumbing (no GPU in this process, BZ_BENCH_REHEARSAL=1): process group,
+    barrier + max-over-ranks timing and the single all-gather of packed example blocks (the engine's exact layout)
+    into buffers allocated before the timed region.  Measures nothing about the hot path and says so."""
+    import numpy as np
     import torch
     import torch.distributed as dist
     from betazero_amd import distributed as bd
-    from betazero_amd.engine import build_example_block, unpack_example_block
-    B, NS, R, T, na = args.games or 256, max(1, args.streams), 2, 64, 65
-    Bs = B // NS
-    g = torch.Generator().manual_seed(rank)
-    blocks = []
-    for i in range(NS):
-        ln = torch.randint(40, T - 4, (R, Bs), generator=g, dtype=torch.int32)
-        ln[1] = -1  # second round unfinished
-        arr = {"own": torch.randint(0, 2**62, (R, Bs, T), generator=g, dtype=torch.int64),
-               "opp": torch.zeros((R, Bs, T), dtype=torch.int64), "pi": torch.rand((R, Bs, T, na), generator=g),
-               "z": torch.zeros((R, Bs, T), dtype=torch.int8), "mover": torch.ones((R, Bs, T), dtype=torch.int8),
-               "act": torch.zeros((R, Bs, T), dtype=torch.uint8), "len": ln, "winner": torch.zeros((R, Bs), dtype=torch.int8)}
-        blocks.append(build_example_block(arr, rank * B + i * Bs, world * B, "reversi"))
-    calls = []
-    real = dist.all_gather_into_tensor
+    from betazero_amd.engine import Examples, build_packed_block, packed_block_header, unpack_packed_block
+    B, na, T = args.games or 256, 65, 64
+    g = np.random.default_rng(rank)
+    n_games = B // 6 + rank  # finished games differ by rank: the header's count travels with the block
+    lens = g.integers(40, T - 4, n_games)
+    n = int(lens.sum())
+    ex = Examples(own=g.integers(0, 2**62, n, dtype=np.int64).view(np.uint64), opp=np.zeros(n, np.uint64),
+                  pi=g.random((n, na), dtype=np.float32), z=np.zeros(n, np.int8), mover=np.ones(n, np.int8),
+                  act=np.zeros(n, np.uint8), game=np.concatenate([np.full(k, rank * B + i, np.int64) for i, k in enumerate(lens)]),
+                  ply=np.concatenate([np.arange(k, dtype=np.int32) for k in lens]), size=8)
+    cap = (B // 6 + world) * T
+    buf = bd.GatherBuffers(na, cap, world, "cpu")
+    buf.send.copy_(build_packed_block(ex, cap, "reversi"))
+    calls, allocs = [], []
+    real, real_empty, real_cat = dist.all_gather_into_tensor, torch.empty, torch.cat
     dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
     K = args.steps if args.steps is not None else 2
     dist.barrier()
     t0 = time.perf_counter()
+    torch.empty = lambda *a, **k: (allocs.append("empty"), real_empty(*a, **k))[1]
+    torch.cat = lambda *a, **k: (allocs.append("cat"), real_cat(*a, **k))[1]
     for _ in range(K):
         time.sleep(0.01)  # stands in for a step
-    gathered, sizes = bd.all_gather_example_blocks(blocks)
+    gathered = bd.all_gather_packed(buf.send, buf.out)
+    torch.empty, torch.cat = real_empty, real_cat
     dist.barrier()
     dt = time.perf_counter() - t0
-    rows = sum(len(unpack_example_block(b)) for row in bd.split_gathered(gathered, sizes) for b in row)
+    dist.all_gather_into_tensor = real
+    heads = [packed_block_header(gathered[r]) for r in range(world)]
+    rows = sum(len(unpack_packed_block(gathered[r])) for r in range(world))
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ranks = [None] * world
     dist.all_gather_object(ranks, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": None,
-                                   "device_name": "cpu (rehearsal)", "device_uuid": "", "games_finished": 0.0, "seconds": dt,
+                                   "device_name": "cpu (rehearsal)", "device_uuid": "", "games_finished": float(n_games), "seconds": dt,
                                    "pid": os.getpid()})
     if rank == 0:
         print(json.dumps({"metric": "selfplay_games_per_s", "value": None, "unit": "games/s", "n_gpus": dist.get_world_size(),
@@ -143,8 +149,9 @@ def rehearsal(args, rank, world):
                           "config": {"workload": "CPU rehearsal of the multi-rank plumbing only (no GPU in this "
                                                  "process): launcher, process group, one all-gather, timing"},
                           "ranks": {"backend": "gloo", "world_size": world, "distinct_devices": 0, "per_rank": ranks},
-                          "collectives": len(calls), "block_bytes_per_rank": int(sum(sizes)),
-                          "gathered_bytes": int(gathered.numel()), "pooled_rows": int(rows)}))
+                          "collectives": len(calls), "allocations_in_timed_region": allocs, "block_bytes_per_rank": int(buf.nbytes),
+                          "gathered_bytes": int(gathered.numel()), "pooled_rows": int(rows),
+                          "pooled_games": int(sum(h["n_games"] for h in heads))}))
 
 
 def usable_cores():
@@ -403,9 +410,9 @@ def run_env(ctx, n, K, W):
             "roofline": {"bound": "hbm", "kernel": "k_reversi_step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": 42.0 * n,
-                         "note": "bound by integer VALU issue, not HBM: 482 VALU instructions per step (228 flips + 191 legal mask + "
-                                 "I/O) at 4 cycles per wave64 instruction keep the VALU ~100 % busy "
-                                 "(SQ_ACTIVE_INST_VALU, profiles/r02_pmc_env_sq_pmc.csv)"}}
+                         "note": "bound by integer VALU issue, not HBM: 350 VALU instructions per step (8 x 15 carry-propagation "
+                                 "flips + ~150 legal mask + ~60 I/O and status) at 4 cycles per wave64 instruction keep the "
+                                 "VALU ~100 % busy (SQ_ACTIVE_INST_VALU, profiles/r03_pmc_env_sq_pmc.csv)"}}
 
 
 def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
@@ -455,27 +462,12 @@ def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
             "sims_per_s": cnt["n_sims"] * ctx.world / dt, "counters": cnt}
 
 
-_STREAMS = {}
-
-
-def pipeline_streams(dev, n):
-    """the pipelines' HIP streams, created ONCE per process and reused by every run in it.  torch hands out streams
-    round-robin from a pool, so a second run in the same process would get the pool's next pair -- and that pair is
-    measurably slower on this stack (tools/exp_repeat.py: six identical runs in one process read 166 / 147 / 167 / ... games/s:
-    only the run on the pool's second pair is slow, whatever it runs)."""
-    import torch
-    key = (str(dev), n)
-    if key not in _STREAMS:
-        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
-    return _STREAMS[key]
-
-
 def run_reversi(ctx, args, B, sims, K, W):
     import torch
     import torch.distributed as dist
     from betazero_amd import _lib
-    from betazero_amd.distributed import all_gather_example_blocks
-    from betazero_amd.engine import SelfPlayEngine
+    from betazero_amd import distributed as bd
+    from betazero_amd.engine import PipelinedSelfPlay, packed_block_header, pipeline_stream_info
     from betazero_amd.net import DeviceNet, PolicyValueNet
     L = _lib.lib()
     prec = args.precision or "bf16"
@@ -486,105 +478,103 @@ def run_reversi(ctx, args, B, sims, K, W):
         fake_quantize_fp8_(mod)
     net = DeviceNet.from_module(mod, B, ctx.dev)
     rounds = 2 + (W + K) // 40
-    # NS independent pipelines of B/NS games, each on its own HIP stream: the tree step of one
-    # overlaps the net kernel of the other and their net launches fill each other's tail wave.
+    # NS independent pipelines of B/NS games, each on its own HIP stream (betazero_amd.engine.PipelinedSelfPlay -- the
+    # package's own self-play loop; this file keeps no copy of it): the tree step of one overlaps the net kernel of the
+    # other and their net launches fill each other's tail wave.
     NS = max(1, args.streams)
-    sizes = [B // NS + (1 if i < B % NS else 0) for i in range(NS)]
-    Bs = sizes[0]
-    streams = pipeline_streams(ctx.dev, NS)
-    engs = [SelfPlayEngine("reversi", sizes[i], sims, "net_" + prec, net, temp_moves=8, openings=1, seed=0, rounds=rounds,
-                           game_id_base=ctx.rank * B + sum(sizes[:i]), game_id_stride=ctx.world * B, device=ctx.dev,
-                           stagger=PLIES_PER_GAME if args.mode == "steady" else 0, reuse_subtree=args.reuse_subtree,
+    steady = args.mode == "steady"
+    sp = PipelinedSelfPlay("reversi", B, sims, "net_" + prec, net, pipelines=NS, game_id_base=ctx.rank * B,
+                           game_id_stride=ctx.world * B, device=ctx.dev, temp_moves=8, openings=1, seed=0, rounds=rounds,
+                           stagger=PLIES_PER_GAME if steady else 0, reuse_subtree=args.reuse_subtree,
                            dirichlet_alpha=0.5 if args.dirichlet_eps > 0 else 0.0, dirichlet_eps=args.dirichlet_eps)
-            for i in range(NS)]
-    for e in engs:
-        e.reset_games()
+    engs, Bs = sp.engines, sp.sizes[0]
+    sp.reset_games()
     ctx.sync()
 
     def step():
-        if args.mode == "steady":
-            for e, st in zip(engs, streams):
-                with torch.cuda.stream(st):
-                    e.search()
-                    e.play(True)
-            return
-        for e, st in zip(engs, streams):  # one whole iteration: every game from its opening to the end
-            with torch.cuda.stream(st):
-                e.reset_games()
-        active = True
-        while active:
-            for e, st in zip(engs, streams):
-                with torch.cuda.stream(st):
-                    e.search()
-                    e.play(False)
-            ctx.sync()
-            active = any(e.status()[0] > 0 for e in engs)
+        if steady:
+            sp.step(restart=True)   # one move for every slot; a finished slot starts its next game at once
+        else:
+            sp.run_iteration()      # every game from its opening to the last finished one
 
-    note(f"reversi: engines up ({NS} x {Bs} games, {sims} sims), warm-up {W} steps")
+    note(f"reversi: engines up ({NS} x {Bs} games, {sims} sims; stream probe {pipeline_stream_info(ctx.dev, NS)}), warm-up {W} steps")
     for _ in range(W):
         step()
     ctx.sync()
     note("warm-up done")
-    fin0 = sum(e.status()[1] for e in engs)
-    for e in engs:
-        e.reset_counters()
+    fin0 = sp.status()[1]
+    sp.reset_counters()
     L.bz_profile_reset()
     prof_on = not args.no_kernel_timers
     PROF_CAP = 1 << 18                      # launches a timer slot holds (bz_abi.h)
     prof_steps = K                          # steps whose launches carry timers: all of them unless a soak run overflows the slots
-    if prof_on and args.mode == "steady":   # events exist before the timed loop: it only records them
+    if prof_on and steady:                  # events exist before the timed loop: it only records them
         prof_steps = max(1, min(K, (PROF_CAP - 64) // (NS * (sims + 2))))
         per = prof_steps * NS * (sims + 2) + 64
         for slot in ("tower", "select", "expand_backup", "play"):
             L.bz_profile_reserve(_lib.PROF_SLOTS.index(slot), per)
     L.bz_profile_enable(1 if prof_on else 0)
-    if ctx.world > 1:  # untimed: the first all-gather of a process group sets up RCCL's channels and buffers
-        wdev = ctx.dev if ctx.backend == "nccl" else "cpu"
-        wsend = torch.zeros(1 << 20, dtype=torch.uint8, device=wdev)
-        wrecv = torch.empty(ctx.world << 20, dtype=torch.uint8, device=wdev)
+    buf = None
+    if ctx.world > 1:
+        # both ends of the one exchange exist before the clock starts.  The packed block holds the finished games only;
+        # its capacity (the same on every rank) bounds what W + K steps of the steady-state pool can finish: a slot
+        # finishes a game every ~58 moves -- sized for one every 50, plus 10 steps of slack; a whole iteration: every slot.
+        cap_games = min(rounds * B, -(-B * (W + K + 10) // 50)) if steady else B
+        cdev = ctx.dev if ctx.backend == "nccl" else "cpu"
+        buf = bd.GatherBuffers(sp.na, sp.packed_capacity(cap_games), ctx.world, ctx.dev, cdev)
+        # untimed: the first all-gather of a process group sets up RCCL's channels and buffers
+        wsend = torch.zeros(1 << 20, dtype=torch.uint8, device=cdev)
+        wrecv = torch.empty(ctx.world << 20, dtype=torch.uint8, device=cdev)
         dist.all_gather_into_tensor(wrecv, wsend)
         del wsend, wrecv
     ctx.barrier()
     note(f"timed region: {K} steps")
+    c0t, c0p = time.thread_time(), time.process_time()
     t0 = time.perf_counter()
     for i in range(K):
         if i == prof_steps and prof_on:
             L.bz_profile_enable(0)          # (a relaxed atomic store: no synchronisation, nothing waits)
         step()
+    t_issued = time.perf_counter() - t0     # the host has queued every launch of the K steps
+    c1t = time.thread_time()
     ctx.sync()
-    pooled_bytes = 0
-    if ctx.world > 1:  # the one exchange step: pool this iteration's (s, pi, z) -- ONE all-gather
-        blocks = [e.example_block() for e in engs]
-        if ctx.backend != "nccl":
-            blocks = [b.cpu() for b in blocks]
-        pooled, _ = all_gather_example_blocks(blocks)
-        pooled_bytes = int(pooled.numel())
-        del pooled
+    if ctx.world > 1:  # the one exchange step: pool the finished games' (s, pi, z) -- pack kernels + ONE all-gather
+        bd.gather_packed(sp, buffers=buf)
     ctx.barrier()
     dt = time.perf_counter() - t0
+    c2t, c2p = time.thread_time(), time.process_time()
     L.bz_profile_enable(0)
     note(f"timed region done: {dt:.2f} s")
-    fin1 = sum(e.status()[1] for e in engs)  # status() raises on engine error flags
-    if args.mode == "iteration":
+    fin1 = sp.status()[1]  # status() raises on engine error flags
+    if not steady:
         fin1, fin0 = K * B, 0
     games = float(fin1 - fin0)
     own_games, own_dt = games, dt
-    if ctx.world > 1:
+    # how much of a host core this rank needs (8 ranks share the box's cores with RCCL's proxy threads): CPU time of the
+    # launch thread while it queues the K steps, and of the thread / the whole process over the timed region
+    host = {"launch_thread_cpu_s_while_issuing": c1t - c0t, "issue_wall_s": t_issued,
+            "host_launch_cpu_frac": (c2t - c0t) / dt, "process_cpu_frac": (c2p - c0p) / dt,
+            "launch_cpu_frac_while_issuing": (c1t - c0t) / max(t_issued, 1e-9),
+            "launches_per_s": K * NS * (2 * sims + 4) / dt if steady else None}
+    pooled = None
+    if ctx.world > 1:  # untimed: what the collective delivered (each rank's header carries its own counts)
+        heads = [packed_block_header(buf.out[r]) for r in range(ctx.world)]
+        pooled = {"bytes_received_per_rank": int(buf.out.numel()), "block_bytes_per_rank": int(buf.nbytes),
+                  "cap_rows": int(buf.cap_rows), "rows": int(sum(h["n_rows"] for h in heads)),
+                  "games": int(sum(h["n_games"] for h in heads)), "collectives_in_timed_region": 1}
         t = torch.tensor([dt, games], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, games = float(tmax[0]), float(tsum[1])
-    cnt = {}
-    for e in engs:
-        for k, v in e.counters().items():
-            cnt[k] = cnt.get(k, 0) + v
+    cnt = sp.counters()
     ranks = None
     if ctx.world > 1:  # untimed: which device every rank really held, what it finished and how long it took
         pr = torch.cuda.get_device_properties(ctx.local)
         mine = {"rank": ctx.rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": ctx.local,
                 "device_name": pr.name, "device_uuid": str(getattr(pr, "uuid", "")),
                 "pci_bus_id": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
-                "games_finished": own_games, "seconds": own_dt, "pid": os.getpid()}
+                "games_finished": own_games, "seconds": own_dt, "pid": os.getpid(),
+                "host_launch_cpu_frac": host["host_launch_cpu_frac"], "process_cpu_frac": host["process_cpu_frac"]}
         ranks = [None] * ctx.world
         dist.all_gather_object(ranks, mine)
     if ctx.rank != 0:
@@ -600,8 +590,12 @@ def run_reversi(ctx, args, B, sims, K, W):
                       "pipelines": f"{NS} x {Bs} games on separate HIP streams",
                       **({"supplementary_features": {"reuse_subtree": args.reuse_subtree, "dirichlet_eps": args.dirichlet_eps}}
                          if (args.reuse_subtree or args.dirichlet_eps > 0) else {}),
-                      "parallelism": f"games sharded over {ctx.world} GPU(s), one all-gather of the example blocks"
-                                     + (f" ({pooled_bytes} bytes received per rank)" if pooled_bytes else "")}}
+                      "stream_probe": pipeline_stream_info(ctx.dev, NS),
+                      "parallelism": f"games sharded over {ctx.world} GPU(s), one all-gather of the packed example blocks"
+                                     + (f" ({pooled['bytes_received_per_rank']} bytes received per rank)" if pooled else "")}}
+    out["host"] = host
+    if pooled:
+        out["pooled"] = pooled
     peak = MFMA_PEAK_TFLOPS if prec == "bf16" else 2 * MFMA_PEAK_TFLOPS  # dense fp8 = 5 PF
     kname = ("k_tower_bf16" if prec == "bf16" else "f8::k_tower_fp8") + " (stem + 12 conv3x3 + heads, fused)"
     if prof_on:

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # BZ_HIP_SO: load a diagnostic variant built by betazero_amd.build.build_variant() instead of the
 # product library (needs BZ_ALLOW_EXPERIMENT=1 as well: such builds may time but not compute)
 SO = os.environ.get("BZ_HIP_SO") or os.path.join(HERE, "libbz_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
 GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3
@@ -87,6 +87,9 @@ _SIGS = {
     "bz_selfplay_run": (i32, [vp, i32, vp]),
     "bz_engine_reset_counters": (i32, [vp, vp]),
     "bz_engine_sum_counters": (i32, [vp, vp]),
+    "bz_examples_packed_bytes": (i64, [i32, i64]),
+    "bz_engine_pack_examples": (i32, [vp, vp, i64, i64, i32, vp]),
+    "bz_stream_overlap_probe": (i32, [vp, vp, i32, i32, C.POINTER(C.c_float)]),
     "bz_profile_enable": (i32, [i32]),
     "bz_profile_reserve": (i32, [i32, i64]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),

@@ -13,18 +13,26 @@ from .engine import DeviceExamples, Examples
 
 
 def _first_occurrences(key8, own8, opp8, pi8):
-    """indices (ascending = insertion order) of the rows to keep: the first of every run of EXACTLY equal
-    (own, opp, pi) rows (SL/train.py:45-50 keeps the first of every exactly-equal pair).  Rows are grouped by the
-    kernel's 64-bit content key (stable sort: insertion order inside a group), then every row is compared WITH THE
-    HEAD OF ITS GROUP on the full content: equal -> a duplicate, dropped; different -> two contents sharing a key, kept.
-    A key collision can therefore never drop a distinct row."""
-    sk, order = torch.sort(key8, stable=True)
-    newrun = torch.ones_like(sk, dtype=torch.bool)
-    newrun[1:] = sk[1:] != sk[:-1]
-    heads = newrun.nonzero(as_tuple=True)[0]                 # sorted positions of the group heads
-    head_row = order[heads[torch.cumsum(newrun, 0) - 1]]     # for every sorted position: the row id of its group's head
-    same = (own8[order] == own8[head_row]) & (opp8[order] == opp8[head_row]) & (pi8[order] == pi8[head_row]).all(1)
-    return torch.sort(order[~(same & ~newrun)]).values
+    """indices (ascending = insertion order) of the rows to keep: the first of every set of EXACTLY equal
+    (own, opp, pi) rows -- SL/train.py:45-50 keeps the first of every exactly-equal pair.  Rows are grouped by the
+    kernel's 64-bit content key (stable sort: insertion order inside a group) and every row is compared with the HEAD
+    of its group on the full content: the head is kept, rows equal to it are duplicates and dropped, rows that differ
+    (another content sharing the key) go into the next pass among themselves -- so the result is exact whatever the
+    keys do: a collision can neither drop a distinct row nor keep a duplicate.  With honest keys that is one pass plus
+    one emptiness check."""
+    kept = []
+    cur = torch.arange(key8.numel(), device=key8.device)
+    while cur.numel():
+        sk, o = torch.sort(key8[cur], stable=True)
+        order = cur[o]
+        newrun = torch.ones_like(sk, dtype=torch.bool)
+        newrun[1:] = sk[1:] != sk[:-1]
+        heads = newrun.nonzero(as_tuple=True)[0]                 # sorted positions of the group heads
+        head_row = order[heads[torch.cumsum(newrun, 0) - 1]]     # for every sorted position: the row id of its group's head
+        same = (own8[order] == own8[head_row]) & (opp8[order] == opp8[head_row]) & (pi8[order] == pi8[head_row]).all(1)
+        kept.append(order[newrun])
+        cur = torch.sort(order[~same]).values                    # ascending again: the stable sort keeps insertion order
+    return torch.sort(torch.cat(kept)).values if kept else cur
 
 
 def augment_examples(ex, dedupe=True, device="cuda:0"):

@@ -107,6 +107,46 @@ BZ_EXPORT int32_t bz_profile_intervals(int32_t slot, double* starts_ms, double* 
     return BZ_OK;
 }
 
+// ---- do two streams really run side by side?  (bz_stream_overlap_probe, bz_abi.h)
+// One wave that waits for `ticks` of the 100-MHz wall clock (s_memrealtime); the iteration cap is the exit every
+// wave reaches whatever the clock does.
+__global__ void __launch_bounds__(64) k_spin(unsigned long long ticks, unsigned int* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned int it = 0;
+    while (wall_clock64() - t0 < ticks && it < (1u << 22)) { __builtin_amdgcn_s_sleep(8); ++it; }
+    if (sink && it == 0xFFFFFFFFu) *sink = it;  // never true: keeps the loop observable
+}
+
+BZ_EXPORT int32_t bz_stream_overlap_probe(void* stream_a, void* stream_b, int32_t spin_us, int32_t reps, float* serial_ratio) {
+    BZ_REQUIRE(serial_ratio && spin_us > 0 && spin_us <= 5000 && reps > 0 && reps <= 16, "bz_stream_overlap_probe: bad arguments");
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    BZ_REQUIRE(a != b, "bz_stream_overlap_probe: the two streams are the same stream");
+    hipEvent_t e0, ea, eb;
+    BZ_HIP(hipEventCreate(&e0)); BZ_HIP(hipEventCreate(&ea)); BZ_HIP(hipEventCreate(&eb));
+    const unsigned long long ticks = (unsigned long long)spin_us * 100ULL;
+    float best = 1e30f;
+    int32_t rc = BZ_OK;
+    for (int r = 0; r <= reps && rc == BZ_OK; ++r) {  // (repetition 0 warms the code object up and is not counted)
+        hipError_t e = hipEventRecord(e0, a);
+        if (e == hipSuccess) e = hipStreamWaitEvent(b, e0, 0);  // both spins start behind the same point in time
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, (unsigned int*)nullptr); e = hipGetLastError(); }
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks, (unsigned int*)nullptr); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipEventRecord(ea, a);
+        if (e == hipSuccess) e = hipEventRecord(eb, b);
+        if (e == hipSuccess) e = hipEventSynchronize(ea);
+        if (e == hipSuccess) e = hipEventSynchronize(eb);
+        float ta = 0, tb = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ta, e0, ea);
+        if (e == hipSuccess) e = hipEventElapsedTime(&tb, e0, eb);
+        if (e != hipSuccess) { rc = bz::hip_fail(e, "bz_stream_overlap_probe"); break; }
+        const float ratio = (ta > tb ? ta : tb) * 1000.0f / (float)spin_us;
+        if (r > 0 && ratio < best) best = ratio;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    if (rc == BZ_OK) *serial_ratio = best;
+    return rc;
+}
+
 #ifndef BZ_BUILD_INFO
 #define BZ_BUILD_INFO "unknown"
 #endif

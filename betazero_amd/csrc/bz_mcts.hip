@@ -93,6 +93,7 @@ struct EngineDev {
     u64 *ex_own, *ex_opp; float* ex_pi; int8_t *ex_z, *ex_mover; uint8_t* ex_act; int32_t* ex_len; int8_t* ex_winner;
     u32* root_N; float *root_W, *root_P;
     u64* counters; u64* cnt_slots; int n_cnt_slots; u32* flags;
+    int32_t* pack_off;  // [rounds][B]: first row of a finished game in the packed example block (k_pack_scan)
 };
 
 struct Cnt { u32 v[CNT_N]; };
@@ -1160,6 +1161,85 @@ __global__ void __launch_bounds__(256) k_count_active(EngineDev E) {
     if ((threadIdx.x & 63) == 0 && act) atomicAdd(&E.flags[FLAG_ACTIVE], act);
 }
 
+
+// ---- packed example block (bz_abi.h): the rows of the FINISHED games only, compacted in (round, slot, ply) order
+// behind a 256-byte header -- what the iteration-end all-gather ships.  Two launches: a one-workgroup scan of the
+// games' row counts (first row of every finished game -> pack_off), then one wave per game copies its rows.
+struct PackedHdr {
+    u64 magic, n_rows, n_games, cap_rows, na, game, dropped_rows, bytes;
+    u64 offs[8];  // own, opp, pi, game id, z, mover, act, ply: byte offsets from the start of the block
+    u64 pad[16];
+};
+static_assert(sizeof(PackedHdr) == 256, "packed example header");
+constexpr u64 kPackedMagic = 0x425A50414B000001ULL;  // "BZPAK" + layout version 1
+struct PackedLayout { int64_t offs[8]; int64_t total; };
+
+__global__ void __launch_bounds__(1024) k_pack_scan(EngineDev E, PackedHdr* hdr, PackedLayout L, u64 cap, int append, int game) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 s_games, s_rows_end;
+    const int n = E.rounds * E.B, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool bad = false;
+    u32 carry = 0, games0 = 0;
+    u64 dropped0 = 0;
+    if (append) {  // every thread reads the header before thread 0 rewrites it (barriers below)
+        bad = hdr->magic != kPackedMagic || hdr->cap_rows != cap || hdr->na != (u64)E.na || hdr->bytes != (u64)L.total ||
+              hdr->game != (u64)game;
+        carry = (u32)hdr->n_rows; games0 = (u32)hdr->n_games; dropped0 = hdr->dropped_rows;
+    }
+    if (threadIdx.x == 0) { s_games = 0; s_rows_end = carry; }
+    __syncthreads();
+    u32 total_all = carry;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + (int)threadIdx.x;
+        const int len = i < n ? E.ex_len[i] : -1;
+        const u32 v = len > 0 ? (u32)len : 0u;
+        u32 x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        u32 woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const u32 sw = wsum[w]; tot += sw; if (w < wave) woff += sw; }
+        const u32 first = total_all + woff + x - v;
+        if (i < n) {
+            const bool fits = len >= 0 && !bad && (u64)first + v <= cap;
+            E.pack_off[i] = fits ? (int32_t)first : -1;
+            if (fits) { atomicAdd(&s_games, 1u); atomicMax(&s_rows_end, first + v); }
+        }
+        total_all += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hdr->magic = kPackedMagic; hdr->cap_rows = cap; hdr->na = (u64)E.na; hdr->bytes = (u64)L.total;
+        hdr->game = (u64)game;
+        for (int k = 0; k < 8; ++k) hdr->offs[k] = (u64)L.offs[k];
+        hdr->n_rows = s_rows_end; hdr->n_games = games0 + s_games;
+        hdr->dropped_rows = bad ? ~0ULL : dropped0 + (u64)(total_all - s_rows_end);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_pack_rows(EngineDev E, char* blk, PackedLayout L) {
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= E.rounds * E.B) return;
+    const int off = E.pack_off[i];
+    if (off < 0) return;
+    const int len = E.ex_len[i], round = i / E.B, g = i - round * E.B;
+    const size_t src = (size_t)i * E.t_max;  // [round][slot][ply]
+    u64* own = reinterpret_cast<u64*>(blk + L.offs[0]) + off; u64* opp = reinterpret_cast<u64*>(blk + L.offs[1]) + off;
+    float* pi = reinterpret_cast<float*>(blk + L.offs[2]) + (size_t)off * E.na;
+    int64_t* gid = reinterpret_cast<int64_t*>(blk + L.offs[3]) + off;
+    int8_t* z = reinterpret_cast<int8_t*>(blk + L.offs[4]) + off; int8_t* mv = reinterpret_cast<int8_t*>(blk + L.offs[5]) + off;
+    uint8_t* act = reinterpret_cast<uint8_t*>(blk + L.offs[6]) + off; uint8_t* ply = reinterpret_cast<uint8_t*>(blk + L.offs[7]) + off;
+    const int64_t id = (int64_t)(E.id_base + (u64)round * E.id_stride + (u64)g);
+    for (int t = lane; t < len; t += 64) {
+        own[t] = E.ex_own[src + t]; opp[t] = E.ex_opp[src + t]; gid[t] = id; z[t] = E.ex_z[src + t];
+        mv[t] = E.ex_mover[src + t]; act[t] = E.ex_act[src + t]; ply[t] = (uint8_t)t;
+    }
+    const float* sp = E.ex_pi + src * E.na;  // a game's rows are consecutive at both ends: one straight copy
+    for (int k = lane; k < len * E.na; k += 64) pi[k] = sp[k];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- host side
@@ -1182,7 +1262,7 @@ struct Carver {
 struct Offsets {
     int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, hot,
         path, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
-        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, total;
+        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, pack_off, total;
     int n_cnt_slots;
     int ncap, ecap, na, maxd;
 };
@@ -1235,6 +1315,7 @@ Offsets carve(const bz_engine_cfg& c) {
     o.n_cnt_slots = (int)((B * 16 + 63) / 64) + 4;  // one slot per wave of the widest (group) launch (<= 16 lanes per game)
     o.cnt_slots = k.take((int64_t)o.n_cnt_slots * CNT_N * 8);
     o.flags = k.take(FLAG_N * 4);
+    o.pack_off = k.take(R * B * 4);
     o.total = k.off;
     return o;
 }
@@ -1307,6 +1388,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.root_N = at<u32>(ws, o.root_N); d.root_W = at<float>(ws, o.root_W); d.root_P = at<float>(ws, o.root_P);
     d.counters = at<u64>(ws, o.counters); d.flags = at<u32>(ws, o.flags);
     d.cnt_slots = at<u64>(ws, o.cnt_slots); d.n_cnt_slots = o.n_cnt_slots;
+    d.pack_off = at<int32_t>(ws, o.pack_off);
     bz_engine_layout& l = e->lay;
     l.ex_own = o.ex_own; l.ex_opp = o.ex_opp; l.ex_pi = o.ex_pi; l.ex_z = o.ex_z; l.ex_mover = o.ex_mover;
     l.ex_act = o.ex_act; l.ex_len = o.ex_len; l.ex_winner = o.ex_winner; l.root_N = o.root_N; l.root_W = o.root_W;
@@ -1499,6 +1581,42 @@ BZ_EXPORT int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active
     return BZ_OK;
 }
 
+
+
+namespace {
+PackedLayout packed_layout(int na, int64_t cap) {
+    PackedLayout L{};
+    Carver k;
+    k.take(256);  // header first: a prefix of the block describes the rest
+    const int64_t esz[8] = {8, 8, 4 * (int64_t)na, 8, 1, 1, 1, 1};
+    for (int i = 0; i < 8; ++i) L.offs[i] = k.take(cap * esz[i]);
+    L.total = k.off;
+    return L;
+}
+}  // namespace
+
+BZ_EXPORT int64_t bz_examples_packed_bytes(int32_t na, int64_t cap_rows) {
+    if (na < 1 || na > 4096 || cap_rows < 1 || cap_rows > (int64_t(1) << 31) - 1) { set_error("bz_examples_packed_bytes: bad arguments"); return -1; }
+    return packed_layout(na, cap_rows).total;
+}
+
+/* compact the finished games' rows of this engine into the caller's packed block (append != 0: behind the rows a
+ * previous call -- another engine of the same geometry -- left there) */
+BZ_EXPORT int32_t bz_engine_pack_examples(bz_engine* e, void* packed, int64_t packed_bytes, int64_t cap_rows, int32_t append,
+                                          void* stream) {
+    BZ_REQUIRE(e && packed, "bz_engine_pack_examples: null pointer");
+    BZ_REQUIRE(cap_rows >= 1 && cap_rows <= (int64_t(1) << 31) - 1, "bz_engine_pack_examples: bad capacity");
+    BZ_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 255) == 0, "bz_engine_pack_examples: the block must be 256-byte aligned");
+    const PackedLayout L = packed_layout(e->dev.na, cap_rows);
+    if (packed_bytes < L.total) { set_error("bz_engine_pack_examples: block too small (%lld < %lld)", (long long)packed_bytes, (long long)L.total); return BZ_ENOMEM; }
+    hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->dev, static_cast<PackedHdr*>(packed), L,
+                       (u64)cap_rows, (int)(append != 0), (int)e->cfg.game);
+    BZ_LAUNCH_CHECK("k_pack_scan");
+    const int n = e->dev.rounds * e->dev.B;
+    hipLaunchKernelGGL(k_pack_rows, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, e->dev, static_cast<char*>(packed), L);
+    BZ_LAUNCH_CHECK("k_pack_rows");
+    return BZ_OK;
+}
 
 /* names used by SURVEY.md 8(b) for the same entry points */
 BZ_EXPORT int32_t bz_mcts_select(bz_engine* e, uint32_t sim_index, void* stream) { return bz_engine_select(e, sim_index, stream); }

@@ -99,14 +99,28 @@ def concat_device_examples(parts):
                           parts[0].size)
 
 
+MAX_SIMS, MAX_SIMS_REUSE = 8189, 2045  # BZ_ENGINE_MAX_SIMS / BZ_ENGINE_MAX_SIMS_REUSE (include/bz_abi.h)
+
+
+def check_sims(sims, reuse_subtree=False):
+    """the packed edge record holds node ids in 13 bits: refuse larger searches where they are asked for"""
+    lim = MAX_SIMS_REUSE if reuse_subtree else MAX_SIMS
+    if not 1 <= int(sims) <= lim:
+        raise ValueError(f"sims must be in 1..{lim}" + (" with subtree reuse" if reuse_subtree else "") +
+                         f" (got {sims}): the tree's packed edge record holds at most 8191 nodes per game "
+                         "(BZ_ENGINE_MAX_SIMS / BZ_ENGINE_MAX_SIMS_REUSE in include/bz_abi.h)")
+
+
 class SelfPlayEngine:
     def __init__(self, game, n_games, sims, evaluator="uniform", net=None, c_puct=1.5, temp_moves=0, openings=0,
                  seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0", stagger=0,
                  dirichlet_alpha=0.0, dirichlet_eps=0.0, reuse_subtree=False, ttt_lanes=0):
+        check_sims(sims, reuse_subtree)
         _lib.require_gpu()
         L = _lib.lib()
         self.game = _GAMES[game]
         self.device = torch.device(device)
+        self._streams = {}  # every stream this engine's kernels were launched on (drained before the workspace dies)
         t_max = 9 if self.game == GAME_TTT else 64
         self.cfg = EngineCfg(self.game, n_games, sims, _EVALS[evaluator], c_puct, temp_moves, openings, rounds, t_max,
                              stagger, seed, game_id_base, n_games if game_id_stride is None else game_id_stride,
@@ -134,7 +148,9 @@ class SelfPlayEngine:
         return self.ws[o:o + n].view(dtype).view(*shape)
 
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream
+        st = torch.cuda.current_stream(self.device)
+        self._streams[st.cuda_stream] = st
+        return st.cuda_stream
 
     def _call(self, fn, *args):
         with torch.cuda.device(self.device):
@@ -286,8 +302,25 @@ class SelfPlayEngine:
             if active == 0 or plies >= limit:
                 return plies
 
+    def pack_examples(self, out=None, cap_rows=None, append=False):
+        """finished games' rows -> a packed example block (bz_abi.h "Packed examples": header + compacted rows in
+        (round, slot, ply) order), by two kernels on the current stream; nothing is copied to the host.  `out`: a block
+        from alloc_packed_block() (append=True: add this engine's rows behind those already in it)."""
+        cap = int(cap_rows or self.rounds * self.B * self.t_max)
+        if out is None:
+            assert not append
+            out = alloc_packed_block(self.na, cap, self.device)
+        self._call(_lib.lib().bz_engine_pack_examples, out.data_ptr(), out.numel(), cap, int(append))
+        return out
+
+    def drain(self):
+        """wait for every stream this engine's kernels were launched on"""
+        for st in self._streams.values():
+            st.synchronize()
+
     def __del__(self):
         try:
+            self.drain()  # the caching allocator only knows the stream the workspace was allocated on
             _lib.lib().bz_engine_destroy(self.h)
         except Exception:
             pass
@@ -355,9 +388,16 @@ def unpack_example_block_device(block, geom):
     """device example block -> DeviceExamples of the finished games, entirely on the device: the array views come from
     `geom` (SelfPlayEngine.block_geometry() of an engine with the same configuration -- every rank's engines are built
     alike), the game-id base / stride are read from the block's own header AS DEVICE SCALARS, the row selection is a
-    device-side nonzero().  No byte of the block visits the host."""
+    device-side nonzero().  No example data is copied to the host: the only host visits are the 112-byte header check and
+    the size read-back of nonzero()."""
     R, B, T, na = geom["rounds"], geom["B"], geom["t_max"], geom["na"]
     assert block.numel() == geom["ex_bytes"], "example block of another geometry"
+    # the block's own header must say what `geom` says (a peer built with another configuration can have the same byte
+    # size): magic and words 3..15 (B, rounds, t_max, NA, game, the 8 array offsets) compared on the device
+    want = torch.tensor([EX_MAGIC, B, R, T, na, geom["game"]] + list(geom["offs"]), dtype=torch.int64)
+    got = block[-256:].view(torch.int64)
+    if not torch.equal(torch.cat([got[0:1], got[3:16]]).cpu(), want):
+        raise ValueError("example block does not have the local engine's geometry (header words differ)")
     shapes = {"own": (R, B, T), "opp": (R, B, T), "pi": (R, B, T, na), "z": (R, B, T), "mover": (R, B, T),
               "act": (R, B, T), "len": (R, B), "winner": (R, B)}
     t = {}
@@ -378,17 +418,274 @@ def concat_examples(parts):
                     parts[0].size)
 
 
+# ---------------------------------------------------------------- packed example blocks (include/bz_abi.h)
+PACKED_MAGIC = 0x425A50414B000001
+_PK_FIELDS = (("own", torch.int64), ("opp", torch.int64), ("pi", torch.float32), ("game", torch.int64),
+              ("z", torch.int8), ("mover", torch.int8), ("act", torch.uint8), ("ply", torch.uint8))
+
+
+def packed_layout(na, cap_rows):
+    """(byte offsets of the 8 arrays, total bytes) of a packed example block: 256-byte header, then own, opp, pi,
+    game id, z, mover, act, ply -- each at a multiple of 256 bytes (== bz_examples_packed_bytes)"""
+    offs, off = [], 256
+    for esz in (8, 8, 4 * na, 8, 1, 1, 1, 1):
+        offs.append(off)
+        off += (cap_rows * esz + 255) & ~255
+    return offs, off
+
+
+def alloc_packed_block(na, cap_rows, device="cuda:0"):
+    """an (uninitialised) packed example block: 1-D uint8 tensor, 256-byte aligned"""
+    _, total = packed_layout(na, cap_rows)
+    t = torch.empty(total + 256, dtype=torch.uint8, device=device)
+    pad = (-t.data_ptr()) & 255
+    return t[pad:pad + total]
+
+
+def packed_block_header(block):
+    """the block's header as a dict (ONE 256-byte copy to the host when the block lives on a GPU)"""
+    h = block[:256].cpu().numpy().view(np.uint64)
+    if int(h[0]) != PACKED_MAGIC:
+        raise ValueError("not a betazero_amd packed example block (bad magic)")
+    d = {"n_rows": int(h[1]), "n_games": int(h[2]), "cap_rows": int(h[3]), "na": int(h[4]), "game": int(h[5]),
+         "dropped_rows": int(h[6]), "bytes": int(h[7]), "offs": [int(v) for v in h[8:16]]}
+    if d["dropped_rows"]:
+        raise RuntimeError("packed example block overflow: " +
+                           ("an engine of another geometry was appended" if d["dropped_rows"] == 2**64 - 1 else
+                            f"{d['dropped_rows']} rows of finished games did not fit into cap_rows = {d['cap_rows']}"))
+    return d
+
+
+def _packed_views(block, h):
+    n, na = h["n_rows"], h["na"]
+    out = {}
+    for (name, dt), off in zip(_PK_FIELDS, h["offs"]):
+        per = na if name == "pi" else 1
+        esz = torch.empty((), dtype=dt).element_size()
+        v = block[off:off + n * per * esz].view(dt)
+        out[name] = v.view(n, na) if name == "pi" else v
+    return out
+
+
+def unpack_packed_block_device(block):
+    """packed example block on a GPU -> DeviceExamples (views of its first n_rows rows; one header read-back)"""
+    h = packed_block_header(block)
+    v = _packed_views(block, h)
+    return DeviceExamples(own=v["own"], opp=v["opp"], pi=v["pi"], z=v["z"], mover=v["mover"], act=v["act"], game=v["game"],
+                          ply=v["ply"].to(torch.int32), size=_SIZES[h["game"]])
+
+
+def unpack_packed_block(block):
+    """packed example block (device or host) -> host Examples; only the valid rows are copied"""
+    h = packed_block_header(block)
+    v = {k: t.cpu().numpy() for k, t in _packed_views(block, h).items()}
+    return Examples(own=v["own"].view(np.uint64), opp=v["opp"].view(np.uint64), pi=v["pi"], z=v["z"], mover=v["mover"],
+                    act=v["act"], game=v["game"], ply=v["ply"].astype(np.int32), size=_SIZES[h["game"]])
+
+
+def build_packed_block(ex, cap_rows, game, device="cpu"):
+    """host-side constructor of a packed block from Examples (saved examples, and the CPU rehearsal of the multi-GPU
+    path): the same bytes bz_engine_pack_examples writes for these rows"""
+    n, na = len(ex), int(ex.pi.shape[1])
+    assert n <= cap_rows
+    offs, total = packed_layout(na, cap_rows)
+    block = torch.zeros(total, dtype=torch.uint8)
+    hdr = np.zeros(32, np.uint64)
+    hdr[0:8] = [PACKED_MAGIC, n, len(np.unique(ex.game)), cap_rows, na, _GAMES[game], 0, total]
+    hdr[8:16] = offs
+    block[:256] = torch.from_numpy(hdr.view(np.uint8).copy())
+    src = {"own": ex.own.view(np.int64), "opp": ex.opp.view(np.int64), "pi": ex.pi.astype(np.float32),
+           "game": np.asarray(ex.game, np.int64), "z": ex.z.astype(np.int8), "mover": ex.mover.astype(np.int8),
+           "act": ex.act.astype(np.uint8), "ply": np.asarray(ex.ply).astype(np.uint8)}
+    for (name, dt), off in zip(_PK_FIELDS, offs):
+        a = torch.from_numpy(np.ascontiguousarray(src[name])).view(torch.uint8).reshape(-1)
+        block[off:off + a.numel()] = a
+    return block.to(device)
+
+
+# ---------------------------------------------------------------- pipelined self-play
+_PIPE_STREAMS, _PIPE_INFO, _PIPE_REJECTED = {}, {}, []
+
+
+def stream_overlap_ratio(a, b, spin_us=300, reps=2):
+    """bz_stream_overlap_probe on two torch streams: ~1.0 = they run side by side, ~2.0 = one waits for the other"""
+    r = C.c_float()
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().bz_stream_overlap_probe(a.cuda_stream, b.cuda_stream, spin_us, reps, C.byref(r)))
+    return float(r.value)
+
+
+def pipeline_streams(device="cuda:0", n=2, max_tries=4):
+    """the n HIP streams the pipelines of this process run on: created ONCE per (device, n) and reused by every
+    PipelinedSelfPlay.  torch hands streams out round-robin from a pool and not every pair runs side by side on this
+    stack (profiles/r03_torch_stream_pool_pairs.txt: the third and fourth stream of a process serialise -- 12 % of the
+    headline), so a candidate set is accepted only when bz_stream_overlap_probe sees every two of its streams overlap
+    (two 0.3-ms single-wave kernels behind a common event finish in ~0.3 ms, not ~0.6); otherwise the next set is
+    tried and the best one seen is kept."""
+    dev = torch.device(device)
+    key = (str(dev), n)
+    if key not in _PIPE_STREAMS:
+        tried = []
+        for _ in range(max_tries if n > 1 else 1):
+            st = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            worst = max([stream_overlap_ratio(st[i], st[j]) for i in range(n) for j in range(i + 1, n)], default=1.0)
+            tried.append((worst, st))
+            if worst < 1.5:
+                break
+        best = min(range(len(tried)), key=lambda i: tried[i][0])
+        _PIPE_REJECTED.extend(t[1] for i, t in enumerate(tried) if i != best)  # kept alive: torch would hand them out again
+        _PIPE_STREAMS[key] = tried[best][1]
+        _PIPE_INFO[key] = {"overlap_ratio_of_candidates": [round(t[0], 3) for t in tried], "picked": best}
+    return _PIPE_STREAMS[key]
+
+
+def pipeline_stream_info(device="cuda:0", n=2):
+    """what the probe saw when pipeline_streams() chose its streams (None before the first call)"""
+    return _PIPE_INFO.get((str(torch.device(device)), n))
+
+
+class PipelinedSelfPlay:
+    """The batched self-play of `n_games` concurrent games on one GPU as `pipelines` independent SelfPlayEngines of
+    n_games / pipelines slots, each on its own HIP stream, sharing one net: the tree step of one pipeline overlaps the
+    net launch of the other and their net launches fill each other's tail (the shape the headline is
+    measured on).  Games keep their global ids (slot s of pipeline i = id base + offset_i + s), so the examples are
+    the same rows whatever the number of pipelines.  Batched counterpart of collect_game_data,
+    src/tic_tac_toe/SL/generate_training_games.py:25-38.
+
+    Stream contract: work is issued behind whatever the caller's current stream holds at that moment (weights just
+    updated there are seen); join() makes the caller's current stream wait for the pipelines without blocking the
+    host, and everything that hands data out (status, counters, pack_examples, examples ...) joins first."""
+
+    def __init__(self, game, n_games, sims, evaluator="uniform", net=None, pipelines=2, streams=None, game_id_base=0,
+                 game_id_stride=None, device="cuda:0", **engine_kwargs):
+        assert 1 <= pipelines <= n_games
+        self.device = torch.device(device)
+        self.sizes = [n_games // pipelines + (1 if i < n_games % pipelines else 0) for i in range(pipelines)]
+        self.streams = list(streams) if streams is not None else pipeline_streams(self.device, pipelines)
+        assert len(self.streams) == pipelines
+        stride = n_games if game_id_stride is None else game_id_stride
+        self.engines = [SelfPlayEngine(game, self.sizes[i], sims, evaluator, net, game_id_base=game_id_base + sum(self.sizes[:i]),
+                                       game_id_stride=stride, device=device, **engine_kwargs) for i in range(pipelines)]
+        e0 = self.engines[0]
+        self.B, self.sims, self.na, self.t_max, self.rounds, self.size, self.game = n_games, sims, e0.na, e0.t_max, e0.rounds, e0.size, e0.game
+
+    # ---- stream plumbing
+    def _fork(self):
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            st.wait_stream(cur)
+
+    def join(self):
+        """the caller's current stream waits for everything issued on the pipelines so far (no host block)"""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def sync(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def _each(self, fn):
+        out = []
+        for e, st in zip(self.engines, self.streams):
+            with torch.cuda.stream(st):
+                out.append(fn(e))
+        return out
+
+    # ---- the loop
+    def reset_games(self):
+        self._fork()
+        self._each(lambda e: e.reset_games())
+
+    def step(self, restart=False):
+        """one move for every active slot of every pipeline: search (root expansion + sims simulations) + play.
+        Asynchronous: the host queues each pipeline's launches on its stream and returns."""
+        self._fork()
+        for e, st in zip(self.engines, self.streams):
+            with torch.cuda.stream(st):
+                e.search()
+                e.play(restart)
+
+    def status(self):
+        """(active slots, finished games) over all pipelines; waits for them; raises on engine error flags"""
+        r = self._each(lambda e: e.status())
+        return sum(a for a, _ in r), sum(f for _, f in r)
+
+    def run_iteration(self, max_plies=None):
+        """play every slot's game to termination (one self-play iteration); returns the number of moves"""
+        self.reset_games()
+        plies, limit = 0, max_plies or (12 if self.game == GAME_TTT else 140)
+        while True:
+            self.step(False)
+            plies += 1
+            if self.status()[0] == 0 or plies >= limit:
+                return plies
+
+    def reset_counters(self):
+        self._each(lambda e: e.reset_counters())
+
+    def counters(self):
+        tot = {}
+        for c in self._each(lambda e: e.counters()):
+            for k, v in c.items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    # ---- examples
+    def example_blocks(self):
+        """the engines' raw fixed-capacity example blocks (views into their workspaces)"""
+        self.join()
+        return [e.example_block() for e in self.engines]
+
+    def packed_capacity(self, games=None):
+        """rows a packed block needs for `games` finished games (default: every slot of every round)"""
+        return int((games if games is not None else self.rounds * self.B) * self.t_max)
+
+    def pack_examples(self, out=None, cap_rows=None):
+        """ONE packed example block with the finished games of all pipelines (pipeline order, then round, slot, ply),
+        written by the pack kernels on the caller's current stream behind the pipelines' work; no host visit."""
+        cap = int(cap_rows or self.packed_capacity())
+        if out is None:
+            out = alloc_packed_block(self.na, cap, self.device)
+        self.join()
+        for i, e in enumerate(self.engines):
+            e.pack_examples(out, cap, append=i > 0)
+        return out
+
+    def device_examples(self):
+        return unpack_packed_block_device(self.pack_examples())
+
+    def examples(self):
+        return unpack_packed_block(self.pack_examples())
+
+    def winners(self):
+        self.join()
+        w = [e.winners() for e in self.engines]
+        return np.concatenate([a for a, _ in w], axis=1), np.concatenate([b for _, b in w], axis=1)
+
+    def __del__(self):
+        try:
+            self.sync()
+        except Exception:
+            pass
+
+
 def self_play(game, n_games, sims, net=None, seed=0, evaluator=None, temp_moves=0, openings=0, c_puct=1.5,
               device="cuda:0", game_id_base=0, game_id_stride=None, dirichlet_alpha=0.0, dirichlet_eps=0.0,
-              reuse_subtree=False):
+              reuse_subtree=False, pipelines=None):
     """Play n_games concurrent self-play games to the end on one GPU and return
     (s, pi, z): canonical states int8 [n, size, size], visit-count policies
-    f32 [n, NA], outcomes for the mover int8 [n] -- plus the Examples object."""
+    f32 [n, NA], outcomes for the mover int8 [n] -- plus the Examples object.
+    With a net evaluator the games run as two pipelines on two HIP streams (PipelinedSelfPlay: the shape bench.py
+    measures); `pipelines` overrides.  The rows do not depend on it."""
     if evaluator is None:
         evaluator = "net_bf16" if net is not None else "uniform"
-    eng = SelfPlayEngine(game, n_games, sims, evaluator, net, c_puct, temp_moves, openings, seed, 1, game_id_base,
-                         game_id_stride, device, dirichlet_alpha=dirichlet_alpha, dirichlet_eps=dirichlet_eps,
-                         reuse_subtree=reuse_subtree)
-    eng.run_iteration()
-    ex = eng.examples()
+    if pipelines is None:
+        pipelines = 2 if (evaluator.startswith("net_") and n_games >= 2) else 1
+    sp = PipelinedSelfPlay(game, n_games, sims, evaluator, net, pipelines, game_id_base=game_id_base,
+                           game_id_stride=game_id_stride, device=device, c_puct=c_puct, temp_moves=temp_moves,
+                           openings=openings, seed=seed, rounds=1, dirichlet_alpha=dirichlet_alpha,
+                           dirichlet_eps=dirichlet_eps, reuse_subtree=reuse_subtree)
+    sp.run_iteration()
+    ex = sp.examples()
     return ex.states(), ex.pi, ex.z, ex

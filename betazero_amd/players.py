@@ -121,6 +121,8 @@ class MCTSPlayer(Player):
     / "net_f32" need a betazero_amd.net.DeviceNet (Reversi, any of the reference's board sizes)."""
 
     def __init__(self, symbol, sims=800, net=None, evaluator=None, c_puct=1.5, device="cuda:0"):
+        from .engine import check_sims
+        check_sims(sims)  # a ValueError naming the limit here, not a RuntimeError at the first get_move
         self.symbol, self.sims, self.net, self.c_puct, self.device = symbol, sims, net, c_puct, device
         # evaluator: "uniform" | "hash" | "net_bf16" | "net_f32" | "net_fp8", or a callable (own, opp, kind) -> (logits, value)
         # on CUDA tensors (SelfPlayEngine.search_external): any torch module, e.g. an MLP for tic-tac-toe

@@ -94,8 +94,9 @@ class GraphedTrainStep:
         return torch.stack([loss.detach(), ce.detach(), mse.detach()])
 
     def _capture(self):
-        """3 eager steps on a side stream (library handles, autotuning, optimiser state -- on all-zero boards and a
-        uniform pi with lr scaled to 0 so that the weights do not move), then the capture"""
+        """3 eager steps on a side stream (library handles, autotuning, optimiser state) on the batch __call__ has just
+        placed in the static buffers, with lr scaled to 0 so that the weights do not move and the optimiser state zeroed
+        afterwards; then the capture (which launches nothing: the first real step is the first replay)"""
         self.module.train()
         lrs = [g["lr"] for g in self.optimizer.param_groups]
         for g in self.optimizer.param_groups:
@@ -129,8 +130,15 @@ class GraphedTrainStep:
 
 
 def refresh_device_net(device_net, module):
-    """push the trained weights into the HIP engine's net (bf16-rounded copy for the MFMA path)"""
+    """push the trained weights into the HIP engine's net (bf16-rounded copy for the MFMA path).  Raises
+    FloatingPointError when a parameter is not finite (one isfinite reduction per refresh): the losses of a step are
+    computed BEFORE its optimiser update, so a last step that overflows is invisible in them, and a net with such
+    weights makes every search return garbage (the engine then raises ERR_EVAL_NONFINITE far from the cause)."""
     import copy
+    bad = [n for n, p in module.named_parameters() if not bool(torch.isfinite(p.detach()).all())]
+    if bad:
+        raise FloatingPointError(f"refresh_device_net: non-finite values in {len(bad)} parameter tensor(s), first: {bad[0]}; "
+                                 "the engine's net was NOT updated")
     m = copy.deepcopy(module).cpu()
     m.round_to_bf16_()
     device_net.update(m.flat_params())

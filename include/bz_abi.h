@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 3
+#define BZ_ABI_VERSION 4
 
 enum { BZ_OK = 0, BZ_EINVAL = 1, BZ_EILLEGAL_MOVE = 2, BZ_EHIP = 3, BZ_ENOMEM = 4, BZ_ENOGPU = 5,
        BZ_ESTATE = 6 };
@@ -285,6 +285,32 @@ int32_t bz_engine_play(bz_engine* e, int32_t restart, void* stream);
 #define BZ_ENGINE_ERR_EVAL_NONFINITE 16
 int32_t bz_engine_status(bz_engine* e, void* stream, int32_t* n_active, int64_t* games_finished,
                          int32_t* error_flags);
+/* ------------------------------------------------------------------------ */
+/* Packed examples: the rows of the FINISHED games only, compacted on the    */
+/* device in (round, slot, ply) order -- the batched form of what            */
+/* collect_game_data keeps, src/tic_tac_toe/SL/generate_training_games.py:   */
+/* 30-36 (only complete games reach all_states / all_actions).  This is what */
+/* the iteration-end all-gather ships (one fixed-capacity buffer per rank).  */
+/*                                                                           */
+/* Block = 256-byte header, then eight arrays of cap_rows elements, each     */
+/* starting at a multiple of 256 bytes:                                      */
+/*   header u64[32]: magic 0x425A50414B000001, n_rows, n_games, cap_rows,    */
+/*                   NA, game, dropped_rows, bytes, offs[8]                  */
+/*   own u64, opp u64, pi f32[NA], game id i64, z i8, mover i8, act u8,      */
+/*   ply u8                                                                  */
+/* dropped_rows = rows of finished games that did not fit (0 in a healthy    */
+/* run; ~0 = an append met a block of another geometry); rows [0, n_rows)    */
+/* of every array are valid.                                                 */
+/* ------------------------------------------------------------------------ */
+#define BZ_PACKED_MAGIC 0x425A50414B000001ULL
+int64_t bz_examples_packed_bytes(int32_t na, int64_t cap_rows);
+/* packed: caller-owned device block of >= bz_examples_packed_bytes(NA, cap_rows) bytes, 256-byte aligned.
+ * append == 0: start the block (header + this engine's rows); append != 0: add this engine's rows behind
+ * those already there (the second pipeline of a rank).  Asynchronous on `stream`; calls that fill one block
+ * must be ordered (same stream, or events). */
+int32_t bz_engine_pack_examples(bz_engine* e, void* packed, int64_t packed_bytes, int64_t cap_rows, int32_t append,
+                                void* stream);
+
 /* aliases under the names SURVEY.md 8(b) lists: select / expand+backup of one simulation, and
  * one whole move (search + play) for every active slot */
 int32_t bz_mcts_select(bz_engine* e, uint32_t sim_index, void* stream);
@@ -311,6 +337,12 @@ int32_t bz_profile_reset(void);
 /* start/end (ms, relative to the slot's first event) of every timed launch; launches issued on
  * different streams may overlap in time */
 int32_t bz_profile_intervals(int32_t slot, double* starts_ms, double* ends_ms, int64_t cap, int64_t* n);
+
+/* Do two HIP streams run side by side?  Starts one single-wave kernel that waits spin_us microseconds on each of
+ * them behind a common event and reports max(completion time) / spin_us, best of `reps`: ~1.0 = the streams
+ * overlap, ~2.0 = the second waited for the first (e.g. they share a hardware queue).  The pipelined self-play
+ * (two engines on two streams) picks its stream pair with it.  Synchronises both streams. */
+int32_t bz_stream_overlap_probe(void* stream_a, void* stream_b, int32_t spin_us, int32_t reps, float* serial_ratio);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
-"""N>1 path on CPU: world_size-2 gloo rehearsals of the one collective on the path -- the all-gather
-of the engines' self-describing example blocks (on GPUs the same code runs over RCCL) -- and of
-`python bench.py --gpus 2`, which has to start its two ranks by itself."""
+"""N>1 path on CPU: world_size-2 gloo rehearsals of the one collective on the path -- the all-gather of the ranks'
+packed example blocks (finished games only, fixed capacity, count in the header; on GPUs the same code runs over
+RCCL) into preallocated buffers, the raw-block variant, and `python bench.py --gpus N`, which has to start its
+ranks by itself."""
 import json
 import os
 import socket
@@ -8,6 +9,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,7 +76,7 @@ def _worker(rank, world, port, out):
             ok &= set(ex.game.tolist()) == want  # ids come from each block's own header
             total += n_rows
     calls.clear()
-    pooled = bd.gather_examples([_FakeEngine(b) for b in blocks])
+    pooled = bd.gather_raw_examples([_FakeEngine(b) for b in blocks])
     ok &= len(calls) == 1 and len(pooled) == total
     dist.all_gather_into_tensor = real
     out.put((rank, bool(ok), total))
@@ -93,26 +95,102 @@ def test_all_gather_example_blocks_world2_gloo():
     assert res[0][2] == res[1][2] > 0  # every rank sees the same pooled row count
 
 
-def test_bench_gpus2_starts_its_own_ranks_cpu_rehearsal():
-    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start two ranks itself.  Without a
-    GPU the ranks run the rehearsal leg (BZ_BENCH_REHEARSAL=1: process group, the single all-gather on
-    blocks of the cfg-3 geometry scaled down, barrier + max-over-ranks timing) and rank 0 prints the line."""
-    env = dict(os.environ, BZ_BENCH_REHEARSAL="1", BZ_DIST_BACKEND="gloo")
+def _fake_examples(rank, n_games, t, na, base):
+    """deterministic finished games of rank `rank`: game ids base + i, `t` rows each (fewer for every third game)"""
+    from betazero_amd.engine import Examples
+    g = np.random.default_rng(500 + rank)
+    lens = [t - (i % 3) for i in range(n_games)]
+    n = sum(lens)
+    pi = g.random((n, na), dtype=np.float32)
+    return Examples(own=g.integers(0, 2**62, n, dtype=np.int64).view(np.uint64), opp=g.integers(0, 2**62, n, dtype=np.int64).view(np.uint64),
+                    pi=pi, z=g.integers(-1, 2, n).astype(np.int8), mover=np.full(n, 1 - 2 * (rank % 2), np.int8),
+                    act=g.integers(0, na, n).astype(np.uint8), game=np.concatenate([np.full(k, base + i, np.int64) for i, k in enumerate(lens)]),
+                    ply=np.concatenate([np.arange(k, dtype=np.int32) for k in lens]), size=8)
+
+
+def _packed_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from betazero_amd import distributed as bd
+    from betazero_amd.engine import build_packed_block, packed_block_header, packed_layout, unpack_packed_block
+    na, cap = 65, 400
+    mine = _fake_examples(rank, 3 + 2 * rank, 60, na, 1000 * rank)   # the ranks finished different numbers of games
+    buf = bd.GatherBuffers(na, cap, world, "cpu")                       # both ends allocated BEFORE the exchange
+    buf.send.copy_(build_packed_block(mine, cap, "reversi"))
+    ok = buf.send.numel() == packed_layout(na, cap)[1] == buf.nbytes
+    calls, allocs = [], []
+    real, real_empty, real_cat = dist.all_gather_into_tensor, torch.empty, torch.cat
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    torch.empty = lambda *a, **k: (allocs.append(1), real_empty(*a, **k))[1]
+    torch.cat = lambda *a, **k: (allocs.append(1), real_cat(*a, **k))[1]
+    got = bd.all_gather_packed(buf.send, buf.out)
+    torch.empty, torch.cat, dist.all_gather_into_tensor = real_empty, real_cat, real
+    ok &= len(calls) == 1 and not allocs and got.data_ptr() == buf.out.data_ptr()  # ONE collective, nothing allocated
+    total = 0
+    for r in range(world):
+        want = _fake_examples(r, 3 + 2 * r, 60, na, 1000 * r)
+        h = packed_block_header(got[r])
+        ex = unpack_packed_block(got[r])
+        ok &= h["n_rows"] == len(want) == len(ex) and h["n_games"] == 3 + 2 * r and h["cap_rows"] == cap
+        for f in ("own", "opp", "pi", "z", "mover", "act", "game", "ply"):
+            ok &= bool(np.array_equal(getattr(ex, f), getattr(want, f)))
+        total += len(ex)
+    # an overflowing block must refuse to unpack
+    bad = build_packed_block(mine, cap, "reversi")
+    bad[:256].view(torch.int64)[6] = 5
+    try:
+        unpack_packed_block(bad)
+        ok = False
+    except RuntimeError:
+        pass
+    out.put((rank, bool(ok), total))
+    dist.destroy_process_group()
+
+
+def test_all_gather_packed_blocks_world2_gloo_preallocated():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_packed_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(timeout=60) for p in ps]
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == res[1][2] == sum(60 - (i % 3) for n in (3, 5) for i in range(n))
+
+
+def test_packed_layout_matches_the_library():
+    from betazero_amd import _lib
+    from betazero_amd.engine import packed_layout
+    for na, cap in ((65, 1), (65, 1000), (9, 589824), (65, 262144)):
+        assert _lib.lib().bz_examples_packed_bytes(na, cap) == packed_layout(na, cap)[1]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_gpus_n_starts_its_own_ranks_cpu_rehearsal(world):
+    """`python bench.py --gpus N` (no torchrun, no WORLD_SIZE) must start N ranks itself.  Without a GPU the ranks run
+    the rehearsal leg (BZ_BENCH_REHEARSAL=1: process group, the single all-gather of packed example blocks of the
+    cfg-3 geometry scaled down into buffers allocated before the clock, barrier + max-over-ranks timing) and rank 0
+    prints the line.  N = 8 is the shape of the driver's scaling run (one GPU box allows at most 6 processes on its
+    card, so the 8-rank case is rehearsed here; profiles/ holds the 6-rank run on one card)."""
+    env = dict(os.environ, BZ_BENCH_REHEARSAL="1", BZ_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--games", "64"], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                        "--games", "64"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["collectives"] == 1
-    assert out["gathered_bytes"] == 2 * out["block_bytes_per_rank"] and out["pooled_rows"] > 0
+    assert out["n_gpus"] == world and out["rehearsal"] is True and out["collectives"] == 1
+    assert out["allocations_in_timed_region"] == []  # nothing is allocated between t0 and dt
+    assert out["gathered_bytes"] == world * out["block_bytes_per_rank"] and out["pooled_rows"] > 0
     # the line proves its own ranks: backend, one entry per rank with the device it held, what it finished and its own clock
     rk = out["ranks"]
-    assert rk["backend"] == "gloo" and rk["world_size"] == 2 and [r["rank"] for r in rk["per_rank"]] == [0, 1]
-    assert len({r["pid"] for r in rk["per_rank"]}) == 2
+    assert rk["backend"] == "gloo" and rk["world_size"] == world and [r["rank"] for r in rk["per_rank"]] == list(range(world))
+    assert len({r["pid"] for r in rk["per_rank"]}) == world
     assert all(set(("local_rank", "device_index", "device_uuid", "games_finished", "seconds")) <= set(r) for r in rk["per_rank"])
+    assert out["pooled_games"] == sum(int(r["games_finished"]) for r in rk["per_rank"])  # every rank's count arrived in its header
 
 
 def test_bench_refuses_gpu_count_mismatch():

@@ -488,8 +488,9 @@ def test_d4_augmentation_and_dedupe_match_the_reference_transforms():
 
 
 def test_device_resident_pipeline_gather_augment_train_never_visits_the_host(monkeypatch):
-    """all_gather_example_blocks -> unpack -> augment_examples -> train_step up to loss.backward() with every
-    device-to-host door bolted (Tensor.cpu / numpy / tolist / item raise): the rows stay on the GPU the whole way
+    """pack kernels -> all_gather_packed -> unpack -> augment_examples -> train_step up to loss.backward() with every
+    device-to-host door bolted (Tensor.cpu / numpy / tolist / item raise; only a packed block's 256-byte header -- the
+    row count -- may cross): the rows stay on the GPU the whole way
     (the pipeline of SL/train.py:24-52 then :85-136).  The device rows equal the host path's rows, before and after
     augmentation + dedupe."""
     import torch.distributed as dist
@@ -516,7 +517,9 @@ def test_device_resident_pipeline_gather_augment_train_never_visits_the_host(mon
         with monkeypatch.context() as mp:
             for name in ("cpu", "numpy", "tolist", "item"):
                 def raiser(self, *a, _n=name, _orig=getattr(torch.Tensor, name), **k):
-                    if self.is_cuda:  # (Adam's step counter is a host tensor: its .item() moves nothing off the GPU)
+                    # (Adam's step counter is a host tensor: its .item() moves nothing off the GPU.  The one device read
+                    # that IS part of the path: a packed block's 256-byte header -- the row count -- per gathered rank)
+                    if self.is_cuda and not (_n == "cpu" and self.dtype == torch.uint8 and self.numel() == 256):
                         raise AssertionError(f"Tensor.{_n}() on a device tensor inside the device-resident pipeline")
                     return _orig(self, *a, **k)
                 mp.setattr(torch.Tensor, name, raiser)
@@ -974,17 +977,22 @@ def _legal_per_oracle(own, opp, act):
     return all(orc.reversi_legal(int(o), int(p)) >> int(a) & 1 for o, p, a in zip(own, opp, act))
 
 
-@pytest.mark.parametrize("stagger", [0, 58], ids=["openings", "all_game_phases"])
-def test_cfg3_full_size_4096_games_800_sims_bf16_net_invariants(stagger):
+@pytest.mark.parametrize("ev,B,stagger", [("net_bf16", 4096, 0), ("net_bf16", 4096, 58), ("net_fp8", 8192, 58)],
+                         ids=["openings", "all_game_phases", "cfg5_selfplay_fp8_8192_games"])
+def test_cfg3_full_size_4096_games_800_sims_bf16_net_invariants(ev, B, stagger):
     """BASELINE cfg 3 exactly as bench.py runs it (4096 concurrent games, 800 sims/move, bf16 MFMA net in
     the loop, packed leaves) for two moves: no error flag, every root's visits sum to 800, pi == N/800 bit
     for bit and sums to 1, every played action legal per the oracle's rules, and the work counters add up:
     one net evaluation per expanded node, one env step per created node, and (from the openings, where no
     search reaches a terminal position) exactly sims + 1 net evaluations per search."""
     from betazero_amd.net import DeviceNet
-    B, sims = 4096, 800
-    dn = DeviceNet.from_module(_net(128, 6, bf16=True), B)
-    eng = _engine("reversi", B, sims, "net_bf16", net=dn, temp_moves=8, openings=1, seed=0, stagger=stagger, rounds=2)
+    sims = 800
+    mod = _net(128, 6, bf16=True)
+    if ev == "net_fp8":  # bench.py's secondary.cfg5_selfplay: the fp8 MFMA tower as the in-loop evaluator of 8192 games
+        from betazero_amd.quant import fake_quantize_fp8_
+        fake_quantize_fp8_(mod)
+    dn = DeviceNet.from_module(mod, B)
+    eng = _engine("reversi", B, sims, ev, net=dn, temp_moves=8, openings=1, seed=0, stagger=stagger, rounds=2)
     eng.reset_games()
     eng.reset_counters()
     roots = 0
@@ -1593,6 +1601,116 @@ def test_examples_do_not_depend_on_how_the_games_are_sharded():
                 assert np.array_equal(a.pi[ma].view(np.uint32), b.pi[mb].view(np.uint32)) and np.array_equal(a.z[ma], b.z[mb]), (ev, gid)
 
 
+def _rows_equal(a, b, what):
+    assert np.array_equal(a.game, b.game) and np.array_equal(a.ply, b.ply), what
+    assert np.array_equal(a.own, b.own) and np.array_equal(a.opp, b.opp) and np.array_equal(a.act, b.act), what
+    assert np.array_equal(a.pi.view(np.uint32), b.pi.view(np.uint32)), what
+    assert np.array_equal(a.z, b.z) and np.array_equal(a.mover, b.mover), what
+
+
+@pytest.mark.parametrize("ev,B", [("net_bf16", 48), ("net_bf16", 61), ("net_fp8", 32)], ids=["bf16_48", "bf16_ragged_61", "fp8_32"])
+def test_pipelined_self_play_two_streams_equals_the_engines_run_alone(ev, B):
+    """The shape the headline is measured on -- two engines sharing ONE DeviceNet, interleaved on two HIP streams
+    (betazero_amd.engine.PipelinedSelfPlay, what bench.py and self_play() run) -- for a whole iteration, against the
+    SAME two engines run alone, one after the other, on the default stream: identical examples bit for bit (game ids,
+    positions, actions, pi bits, z, movers), i.e. sharing the net's workspace and interleaving on the chip changes no
+    result.  Also through the packed block (pack kernels) vs the raw-block unpack, and one engine of all B games."""
+    from betazero_amd.engine import PipelinedSelfPlay, concat_examples, packed_block_header
+    from betazero_amd.net import DeviceNet
+    sims = 24
+    mod = _net(128, 6, bf16=True) if ev == "net_fp8" else _net(64, 2, bf16=True)
+    if ev == "net_fp8":
+        from betazero_amd.quant import fake_quantize_fp8_
+        fake_quantize_fp8_(mod)
+    dn = DeviceNet.from_module(mod, B)
+    kw = dict(temp_moves=8, openings=1, seed=3)
+    sp = PipelinedSelfPlay("reversi", B, sims, ev, dn, pipelines=2, game_id_base=100, game_id_stride=1000, **kw)
+    assert len({s.cuda_stream for s in sp.streams}) == 2 and 0 not in {s.cuda_stream for s in sp.streams}
+    plies = sp.run_iteration()
+    assert plies >= 50 and sp.status() == (0, B)
+    blk = sp.pack_examples()
+    got = sp.examples()
+    h = packed_block_header(blk)
+    assert h["n_games"] == B and h["n_rows"] == len(got) and h["dropped_rows"] == 0
+    raw = concat_examples([e.examples() for e in sp.engines])  # the raw fixed-capacity blocks, unpacked the old way
+    _rows_equal(got, raw, "packed vs raw unpack")
+    alone = []
+    for i, n in enumerate(sp.sizes):  # the same two engines, alone, default stream, one after the other
+        e = _engine("reversi", n, sims, ev, net=dn, game_id_base=100 + sum(sp.sizes[:i]), game_id_stride=1000, **kw)
+        e.run_iteration()
+        alone.append(e.examples())
+    _rows_equal(got, concat_examples(alone), "two streams vs alone")
+    whole = _engine("reversi", B, sims, ev, net=dn, game_id_base=100, game_id_stride=1000, **kw)
+    whole.run_iteration()
+    _rows_equal(got, whole.examples(), "two pipelines vs one engine of all games")
+    assert sorted(set(got.game)) == list(range(100, 100 + B))
+
+
+def test_pipelined_self_play_fp32_net_two_streams_vs_oracle_games():
+    """the same interleaved shape with the exact-fp32 net: every game equals the oracle's game (actions, pi bits, z)"""
+    from betazero_amd.engine import PipelinedSelfPlay
+    from betazero_amd.net import DeviceNet
+    m = _net(32, 2, seed=4)
+    B, sims = 10, 20
+    dn, on = DeviceNet.from_module(m, B), orc.Net(32, 2, 64, m.flat_params())
+    sp = PipelinedSelfPlay("reversi", B, sims, "net_f32", dn, pipelines=2, game_id_base=40, game_id_stride=64, temp_moves=6,
+                           openings=1, seed=9)
+    sp.run_iteration()
+    ex = sp.examples()
+    winners, lens = sp.winners()
+    for g in range(B):
+        r = orc.selfplay_game(orc.GAME_REVERSI, 40 + g, sims, orc.EVAL_NET_F32, 6, 1, 9, net=on)
+        mk = ex.game == 40 + g
+        assert lens[0, g] == len(r["own"]) and winners[0, g] == r["winner"], g
+        assert np.array_equal(ex.own[mk], r["own"]) and np.array_equal(ex.act[mk], r["act"]), g
+        assert np.array_equal(ex.pi[mk].view(np.uint32), r["pi"].view(np.uint32)) and np.array_equal(ex.z[mk], r["z"]), g
+
+
+def test_self_play_entry_runs_the_pipelined_shape_and_pack_overflow_is_loud():
+    """self_play() -- the batched collect_game_data (generate_training_games.py:25-38) -- runs two pipelines with a net
+    evaluator and returns the rows a single engine returns; a packed block that is too small says so instead of
+    dropping rows silently; the stream pair was chosen by the overlap probe."""
+    from betazero_amd.engine import (PipelinedSelfPlay, packed_block_header, pipeline_stream_info, pipeline_streams,
+                                     self_play, stream_overlap_ratio)
+    from betazero_amd.net import DeviceNet
+    dn = DeviceNet.from_module(_net(64, 2, bf16=True), 16)
+    s, pi, z, ex = self_play("reversi", 16, 10, net=dn, seed=5, temp_moves=4, openings=1)
+    s1, pi1, z1, ex1 = self_play("reversi", 16, 10, net=dn, seed=5, temp_moves=4, openings=1, pipelines=1)
+    _rows_equal(ex, ex1, "self_play with 2 pipelines vs 1")
+    assert s.shape == (len(ex), 8, 8) and pi.shape == (len(ex), 65) and np.array_equal(z, ex.z)
+    st = pipeline_streams(DEV, 2)
+    info = pipeline_stream_info(DEV, 2)
+    assert info is not None and stream_overlap_ratio(st[0], st[1]) < 1.5, info  # the chosen pair really overlaps
+    sp = PipelinedSelfPlay("reversi", 8, 6, "hash", pipelines=2, openings=1)
+    sp.run_iteration()
+    small = sp.pack_examples(cap_rows=100)  # 8 games x ~58 rows do not fit
+    with pytest.raises(RuntimeError, match="did not fit"):
+        packed_block_header(small)
+    with pytest.raises(ValueError, match="sims must be in 1..8189"):
+        _engine("reversi", 4, 9000, "hash")
+
+
+def test_pipeline_streams_probe_rejects_a_serialising_pair_in_a_fresh_process():
+    """profiles/r04_stream_pair_probe.txt: the third and fourth stream torch hands out in a process serialise with each
+    other (probe ratio 2.05 against 1.03 for every other pair; 158 against 171 games/s).  A fresh process that has
+    already taken two streams from the pool gets exactly that pair as its first candidate: pipeline_streams() must see
+    it (bz_stream_overlap_probe) and move on, whatever the first candidate measured."""
+    import subprocess
+    import sys
+    code = ("import sys, json, torch; sys.path.insert(0, %r)\n"
+            "from betazero_amd.engine import pipeline_streams, pipeline_stream_info, stream_overlap_ratio\n"
+            "taken = [torch.cuda.Stream(device='cuda:0') for _ in range(2)]\n"
+            "st = pipeline_streams('cuda:0', 2)\n"
+            "print(json.dumps({'info': pipeline_stream_info('cuda:0', 2), 'picked_ratio': stream_overlap_ratio(st[0], st[1])}))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print("stream probe in a process whose pool had handed out two streams:", out)
+    cand = out["info"]["overlap_ratio_of_candidates"]
+    assert out["picked_ratio"] < 1.5 and cand[out["info"]["picked"]] < 1.5
+    assert all(c >= 1.5 for c in cand[:out["info"]["picked"]])  # everything before the pick was rejected for a reason
+
+
 def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     """`python bench.py --gpus 2` for real -- two rank processes with real engines, the timed region, the ONE all-gather
     of the example blocks, max-over-ranks timing and the per-rank proof -- as far as one GPU allows: the ranks share the
@@ -1618,6 +1736,9 @@ def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     assert abs(sum(p["games_finished"] for p in rk["per_rank"]) / max(p["seconds"] for p in rk["per_rank"]) - out["value"]) \
         <= 0.02 * out["value"] + 1e-9  # value = all ranks' games / the slowest rank's time
     assert "bytes received per rank" in out["config"]["parallelism"]
+    # the exchange: finished games only, buffers allocated before the clock, every rank's count arrived in its header
+    assert out["pooled"]["collectives_in_timed_region"] == 1 and out["pooled"]["games"] >= sum(p["games_finished"] for p in rk["per_rank"])
+    assert 0 < out["host"]["host_launch_cpu_frac"] and out["pooled"]["bytes_received_per_rank"] == 2 * out["pooled"]["block_bytes_per_rank"]
     if torch.cuda.device_count() < 2:  # RCCL needs one device per rank: a clear refusal, not a crash inside init
         r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         assert r2.returncode != 0 and "GPU(s) visible" in (r2.stderr + r2.stdout)

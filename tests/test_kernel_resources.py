@@ -41,7 +41,7 @@ def test_tree_kernels_stay_within_their_register_budget(tmp_path):
     res = _resources("bz_mcts.hip", tmp_path)
     step = _find(res, "k_tree_step", "ReversiTILi8")          # cfg 3's tree step: 4+ waves per SIMD
     assert step["vgpr"] <= 96 and step["vspill"] == 0 and step["sspill"] == 0 and step["scratch"] == 0, step
-    for gw, cap in (("ILi2E", 128), ("ILi4E", 128)):          # cfg 2's fused search (2 lanes per game is the default)
+    for gw, cap in (("ILi2E", 128), ("ILi4E", 128)):          # cfg 2's fused search (4 lanes per game is the default since round 3)
         for uni in ("Lb1E", "Lb0E"):                           # uniform evaluator (cfg 2) / hash evaluator
             k = _find(res, "k_search_fused_ttt", gw + uni)
             assert k["vgpr"] <= cap and k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0, (gw, uni, k)

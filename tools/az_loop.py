@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The closed AlphaZero loop on one GPU, end to end through the package's public pieces:
 
-    self-play (SelfPlayEngine, bf16 MFMA net in the loop, Dirichlet root noise, temperature moves)
+    self-play (PipelinedSelfPlay: two engines on two streams, bf16 MFMA net in the loop, Dirichlet root noise, temperature moves)
       -> example block -> 8-fold D4 augmentation + exact dedupe on the device (augment_examples)
       -> policy cross-entropy + value MSE steps with stock PyTorch autograd under bf16 autocast (train_step)
          -- the rows never leave the GPU between the engine's example block and the optimiser step
@@ -26,7 +26,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from betazero_amd.arena import play_arena  # noqa: E402
 from betazero_amd.augment import augment_examples  # noqa: E402
-from betazero_amd.engine import SelfPlayEngine, concat_device_examples  # noqa: E402
+from betazero_amd.engine import PipelinedSelfPlay, concat_device_examples  # noqa: E402
 from betazero_amd.net import DeviceNet, PolicyValueNet  # noqa: E402
 from betazero_amd.train import GraphedTrainStep, make_optimizer, refresh_device_net, train_step  # noqa: E402
 
@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=4)
     ap.add_argument("--games", type=int, default=2048, help="concurrent self-play games per iteration")
     ap.add_argument("--sims", type=int, default=64)
+    ap.add_argument("--pipelines", type=int, default=2, help="self-play pipelines on separate HIP streams (PipelinedSelfPlay)")
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--window", type=int, default=3, help="iterations of examples kept for training")
     ap.add_argument("--epochs", type=float, default=1.0, help="passes over the (augmented) window per iteration")
@@ -88,16 +89,16 @@ def main():
     window = []
     for it in range(1, args.iters + 1):
         t0 = time.time()
-        eng = SelfPlayEngine("reversi", args.games, args.sims, "net_bf16", dnet, temp_moves=args.temp_moves, openings=1,
-                             seed=args.seed * 1000 + it, dirichlet_alpha=0.3, dirichlet_eps=0.25)
-        plies = eng.run_iteration()
-        ex = eng.device_examples()   # finished games' rows, on the device
-        winners, _ = eng.winners()
+        sp = PipelinedSelfPlay("reversi", args.games, args.sims, "net_bf16", dnet, pipelines=args.pipelines, temp_moves=args.temp_moves,
+                               openings=1, seed=args.seed * 1000 + it, dirichlet_alpha=0.3, dirichlet_eps=0.25)
+        plies = sp.run_iteration()
+        ex = sp.device_examples()    # finished games' rows, packed on the device
+        winners, _ = sp.winners()
         torch.cuda.synchronize()
         t_play = time.time() - t0
         t1 = time.time()
         aug = augment_examples(ex, dedupe=True)
-        del eng
+        del sp
         window = (window + [aug])[-args.window:]
         data = concat_device_examples(window)
         steps = max(1, int(args.epochs * len(data) / args.batch))
