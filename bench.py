@@ -43,6 +43,7 @@ NET_FLOP_PER_POS = 226.86e6                           # stem + t
 MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md (fp8: 2x)
 HBM_PEAK_GBS = 8000.0
 PLIES_PER_GAME = 58                                   # searched moves per cfg-3 game (60 - 2 opening plies)
+WHOLE_GAME_SIMS = 32                                  # cpu_baseline.whole_game: complete games on the C port at this many sims/move
 PMC_TRAFFIC = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
 
 
@@ -223,6 +224,40 @@ def cpu_baseline_reversi(sims, budget_s=12.0):
     out = {"value": sum(done) / dt / PLIES_PER_GAME, "unit": "games/s", "cores": cores, "kind": "port",
            "sample": f"{cores} threads x {moves} searched moves ({sims} sims, {sims + 1} net evals per move) of "
                      f"cfg-3 games in {dt:.1f} s; extrapolated at {PLIES_PER_GAME} searched moves per game"}
+    # (i-b) the extrapolation checked against WHOLE games: every thread plays one complete cfg-3 game (its own game id:
+    # openings, tau = 1 sampling and therefore move counts and branching differ) at a reduced, stated number of
+    # simulations, and the same game's first two searched moves again on their own -- the ratio says what "2 moves x 29"
+    # over- or under-states against a game's real profile (late searches reach terminal leaves, which cost no net call)
+    ws = WHOLE_GAME_SIMS
+    whole = [None] * cores
+
+    def work_whole(i):
+        t0 = time.time()
+        r2 = orc.selfplay_game(orc.GAME_REVERSI, i, ws, orc.EVAL_NET_BF16, 8, 1, 0, net=net, max_moves=moves)
+        t2 = time.time() - t0
+        t0 = time.time()
+        r = orc.selfplay_game(orc.GAME_REVERSI, i, ws, orc.EVAL_NET_BF16, 8, 1, 0, net=net)
+        whole[i] = (len(r["own"]), time.time() - t0, len(r2["own"]), t2, r["counters"]["n_net_leaves"], r["passes"])
+    t0 = time.time()
+    th = [threading.Thread(target=work_whole, args=(i,)) for i in range(cores)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dtw = time.time() - t0
+    mv = [w[0] for w in whole]
+    extrap = [w[3] / max(w[2], 1) * w[0] for w in whole]          # per game: its 2-move sample scaled to its own move count
+    extrap58 = [w[3] / max(w[2], 1) * PLIES_PER_GAME for w in whole]  # ... and at the fixed 58 the headline extrapolation uses
+    ratio = sum(w[1] for w in whole) / sum(extrap)
+    ratio58 = sum(w[1] for w in whole) / sum(extrap58)
+    out["whole_game"] = {"value": cores / (sum(w[1] for w in whole) / cores), "unit": "games/s", "cores": cores, "kind": "port",
+                         "sims": ws, "games": cores, "searched_moves_per_game": {"mean": sum(mv) / len(mv), "min": min(mv), "max": max(mv)},
+                         "net_evals_per_game_mean": sum(w[4] for w in whole) / cores, "passes_total": sum(w[5] for w in whole),
+                         "whole_game_s_over_two_move_sample_scaled_to_its_moves": ratio,
+                         "whole_game_s_over_two_move_sample_x_58": ratio58,
+                         "sample": f"{cores} threads x 1 COMPLETE cfg-3 game each at {ws} sims/move (+ the same game's first {moves} "
+                                   f"searched moves again on their own) in {dtw:.1f} s"}
+    out["value_corrected_by_whole_game_profile"] = out["value"] / ratio58
+    out["sample"] += (f"; whole games at {ws} sims take {ratio58:.2f} x what their first {moves} moves x {PLIES_PER_GAME} / {moves} predict "
+                      f"(cpu_baseline.whole_game), so the extrapolated figure is a LOWER bound on the port's speed by about that factor")
     # the same port on ONE thread (1 thread and all cores)
     t0 = time.time()
     r1 = orc.selfplay_game(orc.GAME_REVERSI, 0, sims, orc.EVAL_NET_BF16, 8, 1, 0, net=net, max_moves=1)
@@ -263,21 +298,23 @@ def cpu_baseline_reversi(sims, budget_s=12.0):
     return out
 
 
-def cfg1_python_loop(n_games=100, sims=25):
+def cfg1_python_loop(n_games=100, sims=25, temp_moves=2):
     """BASELINE cfg 1 (plumbing, CPU): the build-authored Python MCTS (oracle/py_twin.py -- the reference has no MCTS,
     SURVEY 0 F2) over betazero_amd's API-compatible TicTacToeBoard, 25 sims/move, uniform priors, seed 0, 100 games,
-    ONE core; every game must be legal and finish.  The trajectory loop has the semantics of the reference's
+    ONE core; every game must be legal and finish.  The first `temp_moves` moves of a game are sampled ~ N (tau = 1,
+    counter RNG keyed by the game id) so that the 100 games are 100 different games, not one game 100 times.  The trajectory loop has the semantics of the reference's
     TicTacToeHeadless.play (src/tic_tac_toe/tic_tac_toe.py:13-34): position recorded before every move, winner from
     is_game_over."""
     py_twin = _py_twin()
     import betazero_amd as bz
     tw = py_twin.Twin("ttt", "uniform", boards=(bz.ReversiBoard, bz.TicTacToeBoard))
     t0 = time.time()
-    plies, res, legal = 0, {1: 0, -1: 0, 0: 0}, True
+    plies, res, legal, distinct = 0, {1: 0, -1: 0, 0: 0}, True, set()
     for g in range(n_games):
-        ex, w, _ = tw.selfplay(g, sims, 0, 0, 0)
+        ex, w, _ = tw.selfplay(g, sims, temp_moves, 0, 0)
         plies += len(ex)
         res[w] += 1
+        distinct.add(tuple(e[4] for e in ex))
         # replay through the board API: every recorded action legal, the game really over, the winner as recorded
         b, p = bz.TicTacToeBoard(), 1
         for (_own, _opp, _pi, mover, a) in ex:
@@ -291,7 +328,8 @@ def cfg1_python_loop(n_games=100, sims=25):
             "config": {"workload": f"ttt3x3_{n_games}games_{sims}sims_python_loop_cpu",
                        "loop": "build-authored Python MCTS (oracle/py_twin.py) over betazero_amd.TicTacToeBoard; "
                                "the reference has no MCTS loop to time"},
-            "games": n_games, "plies_per_game": plies / n_games, "results_x_o_draw": [res[1], res[-1], res[0]],
+            "games": n_games, "temp_moves": temp_moves, "distinct_move_sequences": len(distinct),
+            "plies_per_game": plies / n_games, "results_x_o_draw": [res[1], res[-1], res[0]],
             "all_games_legal_and_finished": bool(legal), "seconds": dt}
 
 
@@ -485,7 +523,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     steady = args.mode == "steady"
     sp = PipelinedSelfPlay("reversi", B, sims, "net_" + prec, net, pipelines=NS, game_id_base=ctx.rank * B,
                            game_id_stride=ctx.world * B, device=ctx.dev, temp_moves=8, openings=1, seed=0, rounds=rounds,
-                           stagger=PLIES_PER_GAME if steady else 0, reuse_subtree=args.reuse_subtree,
+                           stagger=PLIES_PER_GAME if steady else 0, reuse_subtree=args.reuse_subtree, run_ahead=args.run_ahead,
                            dirichlet_alpha=0.5 if args.dirichlet_eps > 0 else 0.0, dirichlet_eps=args.dirichlet_eps)
     engs, Bs = sp.engines, sp.sizes[0]
     sp.reset_games()
@@ -552,7 +590,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     own_games, own_dt = games, dt
     # how much of a host core this rank needs (8 ranks share the box's cores with RCCL's proxy threads): CPU time of the
     # launch thread while it queues the K steps, and of the thread / the whole process over the timed region
-    host = {"launch_thread_cpu_s_while_issuing": c1t - c0t, "issue_wall_s": t_issued,
+    host = {"run_ahead_sims": args.run_ahead, "launch_thread_cpu_s_while_issuing": c1t - c0t, "issue_wall_s": t_issued,
             "host_launch_cpu_frac": (c2t - c0t) / dt, "process_cpu_frac": (c2p - c0p) / dt,
             "launch_cpu_frac_while_issuing": (c1t - c0t) / max(t_issued, 1e-9),
             "launches_per_s": K * NS * (2 * sims + 4) / dt if steady else None}
@@ -682,6 +720,9 @@ def main():
                     help="reversi: steady = one move per step on a staggered pool (default); iteration = a step is a\n"
                          "complete self-play iteration from the start position to the last finished game (cross-check)")
     ap.add_argument("--streams", type=int, default=2, help="independent half-batch pipelines per GPU (reversi)")
+    ap.add_argument("--run-ahead", type=int, default=16,
+                    help="simulations the host launch thread may queue ahead of the GPU (PipelinedSelfPlay.run_ahead; 0 = unbounded: "
+                         "the thread then spins on the runtime's full queue, a whole core per rank)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --games per GPU (default, the headline); strong = --games in total, split over the ranks")
     ap.add_argument("--reuse-subtree", action="store_true", help="supplementary: keep the chosen child's subtree (DESIGN 3.10)")
@@ -780,7 +821,8 @@ def main():
                         note(f"secondary {name}")
                         r = fn()
                         sec[name] = {k: r[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "dtype", "config",
-                                                       "roofline", "cores", "games", "plies_per_game", "results_x_o_draw",
+                                                       "roofline", "cores", "games", "plies_per_game", "results_x_o_draw", "host",
+                                                       "temp_moves", "distinct_move_sequences",
                                                        "all_games_legal_and_finished", "seconds") if k in r}
                     except Exception as e:
                         sec[name] = {"error": repr(e)}

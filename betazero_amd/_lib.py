@@ -85,6 +85,7 @@ _SIGS = {
     "bz_mcts_select": (i32, [vp, u32, vp]),
     "bz_mcts_expand_backup": (i32, [vp, vp]),
     "bz_selfplay_run": (i32, [vp, i32, vp]),
+    "bz_engines_step": (i32, [C.POINTER(vp), C.POINTER(vp), i32, i32, i32]),
     "bz_engine_reset_counters": (i32, [vp, vp]),
     "bz_engine_sum_counters": (i32, [vp, vp]),
     "bz_examples_packed_bytes": (i64, [i32, i64]),

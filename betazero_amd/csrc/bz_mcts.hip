@@ -30,6 +30,8 @@
 // reference has none).
 #include <new>
 
+#include <time.h>
+
 #include "bz_common.h"
 #include "bz_math.h"
 #include "bz_rules.h"
@@ -1251,6 +1253,10 @@ struct bz_engine {
     int64_t bytes;
     int pack_parity;  // which NEVAL buffer the last root_begin / select packed into
     int ttt_gw;       // lanes per game of the TTT-specialised fused search (cfg.ttt_lanes; 0 = the generic any-game kernel)
+    // bz_engines_step: ring of blocking-sync events that bounds how far the host thread runs ahead of this engine's
+    // stream (created on first use)
+    hipEvent_t ahead[4];
+    int n_ahead;
 };
 
 namespace {
@@ -1358,7 +1364,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_engine_create: workspace must be 256-byte aligned");
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
-    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1;
+    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1; e->n_ahead = 0;
     // measured on MI355X at 65,536 games x 50 sims: round 2 (profiles/r02_bench_ttt_gw*) 2 lanes 0.185 ms, 4 lanes 0.190 ms,
     // 8 lanes 0.294 ms per launch; round 3, after the kernel became issue-bound and lost a third of its instructions
     // (profiles/r03_bench_ttt_lanes.txt): 1 lane 0.162, 2 lanes 0.137, 4 lanes 0.134, 8 lanes 0.181 ms -> 4 lanes
@@ -1410,7 +1416,11 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_engine_destroy(bz_engine* e) { delete e; return BZ_OK; }
+BZ_EXPORT int32_t bz_engine_destroy(bz_engine* e) {
+    if (e) for (int i = 0; i < e->n_ahead; ++i) (void)hipEventDestroy(e->ahead[i]);
+    delete e;
+    return BZ_OK;
+}
 
 BZ_EXPORT int32_t bz_engine_get_layout(const bz_engine* e, bz_engine_layout* out) {
     BZ_REQUIRE(e && out, "bz_engine_get_layout: null pointer");
@@ -1625,4 +1635,75 @@ BZ_EXPORT int32_t bz_mcts_expand_backup(bz_engine* e, void* stream) { return bz_
 BZ_EXPORT int32_t bz_selfplay_run(bz_engine* e, int32_t restart, void* stream) {
     int32_t rc = bz_engine_search(e, stream);
     return rc != BZ_OK ? rc : bz_engine_play(e, restart, stream);
+}
+
+/* One move (search + play) for several engines at once -- the pipelines of one GPU, each on its own stream -- issued
+ * by ONE host thread, interleaved simulation by simulation, so that every stream always has work queued whatever the
+ * host's run-ahead.  run_ahead_sims > 0 bounds that run-ahead: every run_ahead_sims / 2 simulations the thread records
+ * a blocking-sync event per stream and sleeps on the one recorded two marks earlier.  Without the bound the thread
+ * queues launches until the runtime's queue is full and then spins there: measured 100 % of a core for the whole
+ * timed region (plus a second runtime thread), which eight ranks on one host cannot afford. */
+static int32_t ahead_mark(bz_engine* e, int idx, hipStream_t s) {
+    while (e->n_ahead < 4) {
+        BZ_HIP(hipEventCreateWithFlags(&e->ahead[e->n_ahead], hipEventBlockingSync | hipEventDisableTiming));
+        e->n_ahead++;
+    }
+    BZ_HIP(hipEventRecord(e->ahead[idx & 3], s));
+    if (idx >= 2) {
+        // hipEventSynchronize spins on this stack even for hipEventBlockingSync events (measured: the thread stayed at
+        // 100 % of a core), so the wait is a poll with real sleeps; a mark is many milliseconds of queued GPU work
+        const timespec nap = {0, 100 * 1000};
+        for (;;) {
+            const hipError_t q = hipEventQuery(e->ahead[(idx - 2) & 3]);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return hip_fail(q, "bz_engines_step: hipEventQuery");
+            (void)hipGetLastError();  // hipErrorNotReady is sticky in hipGetLastError
+            nanosleep(&nap, nullptr);
+        }
+    }
+    return BZ_OK;
+}
+
+BZ_EXPORT int32_t bz_engines_step(bz_engine* const* engines, void* const* streams, int32_t n, int32_t restart,
+                                  int32_t run_ahead_sims) {
+    BZ_REQUIRE(engines && streams && n >= 1 && n <= 16 && run_ahead_sims >= 0, "bz_engines_step: bad arguments");
+    bool stepwise = true;
+    for (int i = 0; i < n; ++i) {
+        BZ_REQUIRE(engines[i], "bz_engines_step: null engine");
+        BZ_REQUIRE(engines[i]->cfg.sims == engines[0]->cfg.sims, "bz_engines_step: the engines must search the same number of simulations");
+        const int ek = engines[i]->cfg.eval_kind;
+        BZ_REQUIRE(ek != BZ_EVAL_EXTERNAL, "bz_engines_step: BZ_EVAL_EXTERNAL callers drive the step API");
+        if ((ek == BZ_EVAL_UNIFORM || ek == BZ_EVAL_HASH) && !engines[i]->dev.reuse && !(engines[i]->dev.dir_eps > 0.0f)) stepwise = false;
+    }
+    int32_t rc;
+    if (!stepwise) {  // a fused search is one launch per engine: nothing to interleave
+        for (int i = 0; i < n; ++i)
+            if ((rc = bz_selfplay_run(engines[i], restart, streams[i])) != BZ_OK) return rc;
+        return BZ_OK;
+    }
+    for (int i = 0; i < n; ++i) {
+        bz_engine* e = engines[i];
+        if ((rc = bz_engine_root_begin(e, streams[i])) != BZ_OK) return rc;
+        if ((rc = bz_engine_evaluate(e, streams[i])) != BZ_OK) return rc;
+        if (e->dev.dir_eps > 0.0f) {
+            if ((rc = tree_step(e, 1, 0, 0, streams[i])) != BZ_OK) return rc;
+            if ((rc = bz_engine_root_noise(e, streams[i])) != BZ_OK) return rc;
+        }
+    }
+    const int sims = engines[0]->cfg.sims, q = run_ahead_sims > 0 ? (run_ahead_sims >= 2 ? run_ahead_sims / 2 : 1) : 0;
+    for (int s = 0; s < sims; ++s) {
+        for (int i = 0; i < n; ++i) {
+            bz_engine* e = engines[i];
+            if ((rc = tree_step(e, (e->dev.dir_eps > 0.0f && s == 0) ? 0 : 1, 1, (uint32_t)s, streams[i])) != BZ_OK) return rc;
+            if ((rc = bz_engine_evaluate(e, streams[i])) != BZ_OK) return rc;
+        }
+        if (q && (s + 1) % q == 0)
+            for (int i = 0; i < n; ++i)
+                if ((rc = ahead_mark(engines[i], (s + 1) / q - 1, (hipStream_t)streams[i])) != BZ_OK) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        if ((rc = tree_step(engines[i], 1, 0, 0, streams[i])) != BZ_OK) return rc;
+        if ((rc = bz_engine_play(engines[i], restart, streams[i])) != BZ_OK) return rc;
+    }
+    return BZ_OK;
 }

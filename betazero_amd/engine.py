@@ -557,8 +557,11 @@ class PipelinedSelfPlay:
     host, and everything that hands data out (status, counters, pack_examples, examples ...) joins first."""
 
     def __init__(self, game, n_games, sims, evaluator="uniform", net=None, pipelines=2, streams=None, game_id_base=0,
-                 game_id_stride=None, device="cuda:0", **engine_kwargs):
+                 game_id_stride=None, device="cuda:0", run_ahead=16, **engine_kwargs):
         assert 1 <= pipelines <= n_games
+        # simulations the host thread may queue ahead of the GPU (0 = unbounded: it then spins on the runtime's full queue,
+        # 2 cores per rank against 0.18 -- profiles/r04_host_run_ahead.txt)
+        self.run_ahead = run_ahead
         self.device = torch.device(device)
         self.sizes = [n_games // pipelines + (1 if i < n_games % pipelines else 0) for i in range(pipelines)]
         self.streams = list(streams) if streams is not None else pipeline_streams(self.device, pipelines)
@@ -598,13 +601,18 @@ class PipelinedSelfPlay:
         self._each(lambda e: e.reset_games())
 
     def step(self, restart=False):
-        """one move for every active slot of every pipeline: search (root expansion + sims simulations) + play.
-        Asynchronous: the host queues each pipeline's launches on its stream and returns."""
+        """one move for every active slot of every pipeline: search (root expansion + sims simulations) + play, issued
+        by bz_engines_step: ONE host thread, the pipelines interleaved simulation by simulation, at most `run_ahead`
+        simulations ahead of the streams (it sleeps on blocking events instead of spinning on a full queue).  Returns
+        with the tail of the move still queued."""
         self._fork()
+        n = len(self.engines)
         for e, st in zip(self.engines, self.streams):
-            with torch.cuda.stream(st):
-                e.search()
-                e.play(restart)
+            e._streams[st.cuda_stream] = st
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bz_engines_step((C.c_void_p * n)(*[e.h for e in self.engines]),
+                                                  (C.c_void_p * n)(*[st.cuda_stream for st in self.streams]), n,
+                                                  int(restart), int(self.run_ahead)))
 
     def status(self):
         """(active slots, finished games) over all pipelines; waits for them; raises on engine error flags"""

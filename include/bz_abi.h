@@ -316,6 +316,13 @@ int32_t bz_engine_pack_examples(bz_engine* e, void* packed, int64_t packed_bytes
 int32_t bz_mcts_select(bz_engine* e, uint32_t sim_index, void* stream);
 int32_t bz_mcts_expand_backup(bz_engine* e, void* stream);
 int32_t bz_selfplay_run(bz_engine* e, int32_t restart, void* stream);
+/* one move (search + play) for n engines -- the pipelines of one GPU, engine i on streams[i] -- issued by ONE host
+ * thread and interleaved simulation by simulation.  run_ahead_sims > 0 bounds how far the thread runs ahead of the
+ * streams (it then sleeps on blocking-sync events instead of spinning on a full queue; 0 = unbounded, the behaviour of
+ * bz_selfplay_run called engine by engine).  Results are those of bz_selfplay_run on every engine.  All engines must
+ * search the same number of simulations; n <= 16. */
+int32_t bz_engines_step(bz_engine* const* engines, void* const* streams, int32_t n, int32_t restart,
+                        int32_t run_ahead_sims);
 int32_t bz_engine_reset_counters(bz_engine* e, void* stream);
 /* fold the kernels' per-wave counter slots into the layout's counters[16] array (async) */
 int32_t bz_engine_sum_counters(bz_engine* e, void* stream);
