@@ -91,6 +91,14 @@ _SIGS = {
     "bz_examples_packed_bytes": (i64, [i32, i64]),
     "bz_engine_pack_examples": (i32, [vp, vp, i64, i64, i32, vp]),
     "bz_stream_overlap_probe": (i32, [vp, vp, i32, i32, C.POINTER(C.c_float)]),
+    "bz_train_wf_bytes": (i64, [i32, i32]),
+    "bz_train_positions_per_workgroup": (i32, [i32]),
+    "bz_train_mask_bytes": (i64, [i32, i32, i32]),
+    "bz_train_pack_weights": (i32, [vp, i32, i32, vp, vp, vp]),
+    "bz_train_tower_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "bz_train_tower_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "bz_train_wgrad_splits": (i32, [i32, i32, i32]),
+    "bz_train_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "bz_profile_enable": (i32, [i32]),
     "bz_profile_reserve": (i32, [i32, i64]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),

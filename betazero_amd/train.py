@@ -68,12 +68,23 @@ class GraphedTrainStep:
 
     The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
 
-    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True):
+    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None):
         # (NCHW on purpose: channels-last convolutions measured ~20 % faster per step in tools/bench_train.py, but the
         # closed loop then failed to learn the value head in one run and produced non-finite weights in two others --
         # profiles/r03_az_loop_channels_last_failure.txt -- so that layout is not offered)
         self.module, self.batch, self.dev, self.autocast = module.to(device), batch, torch.device(device), autocast
-        self.optimizer = torch.optim.Adam(module.parameters(), lr=lr, capturable=True)
+        # tower_kernels: run the residual tower's forward / backward on the hand-written HIP kernels (csrc/bz_train.hip)
+        # instead of MIOpen; default: whenever the module keeps its tower stacked (PolicyValueNet(fused_tower=True))
+        if tower_kernels is None:
+            tower_kernels = bool(getattr(module, "fused_tower", False))
+        self.plan = None
+        if tower_kernels:
+            from .train_kernels import TowerPlan
+            if not getattr(module, "fused_tower", False):
+                raise ValueError("tower_kernels=True needs PolicyValueNet(..., fused_tower=True)")
+            self.plan = TowerPlan(module.C, 2 * module.NB, batch, device)
+        # (fused: the whole Adam update of all parameter tensors is one kernel instead of ~10 multi-tensor ones)
+        self.optimizer = torch.optim.Adam(module.parameters(), lr=lr, capturable=True, fused=True)
         self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.pi = torch.full((batch, na), 1.0 / na, dtype=torch.float32, device=self.dev)
@@ -83,7 +94,7 @@ class GraphedTrainStep:
     def _step(self):
         x = planes_from_bits(self.own, self.opp)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
-            logits, v = self.module(x)
+            logits, v = self.module(x, plan=self.plan) if self.plan is not None else self.module(x)
         logits, v = logits.float(), v.float()
         ce = -(self.pi * F.log_softmax(logits, dim=1)).sum(1).mean()
         mse = F.mse_loss(v, self.z.to(torch.float32))

@@ -1,0 +1,140 @@
+"""The residual tower's training step on the hand-written HIP kernels of csrc/bz_train.hip (bz_train_* in
+include/bz_abi.h): forward with saved activations, backward-data, backward-weights -- as ONE torch.autograd.Function,
+so that stem, heads, losses and the optimiser stay plain torch (the loop shape of src/tic_tac_toe/SL/train.py:85-136).
+
+    plan = TowerPlan(C, n_layers, batch)                    # every device buffer of one training shape, allocated once
+    y = tower_apply(x0, W, b, plan)                         # x0 [n, C, 8, 8] = relu(stem(planes)); W [L, C, C, 3, 3]; b [L, C]
+    loss(y).backward()                                      # d/dx0, d/dW, d/db through the kernels
+
+bf16 activations and gradients, fp32 accumulation, fp32 master weights (the kernels repack W into their bf16 fragment
+streams every step -- 2 x 147 k values per layer at C = 128).  There is no CPU path: without the HIP library or a GPU
+this raises; PolicyValueNet falls back to nothing by itself -- it uses these kernels only when asked to (fused_tower)."""
+import torch
+
+from . import _lib
+
+
+class TowerPlan:
+    """device buffers of one (channels, conv layers, batch) training shape:
+    acts / gs [L + 1, n, 64, C] bf16 (act[a], g[a] of bz_abi.h), the ReLU bit masks, the two weight-fragment streams,
+    the weight-gradient partials and C zeros.  Static addresses: a step can be captured into a HIP graph."""
+
+    def __init__(self, channels, n_layers, batch, device="cuda:0"):
+        _lib.require_gpu()
+        L = _lib.lib()
+        self.C, self.L, self.n, self.device = channels, n_layers, batch, torch.device(device)
+        P = L.bz_train_positions_per_workgroup(channels)
+        if P <= 0 or n_layers < 2 or n_layers % 2:
+            raise ValueError("the training kernels are built for 64 or 128 channels and an even number of conv layers")
+        if batch % P:
+            raise ValueError(f"batch must be a multiple of {P} at {channels} channels (positions resident per workgroup)")
+        dev = self.device
+        self.acts = torch.zeros((n_layers + 1, batch, 64, channels), dtype=torch.bfloat16, device=dev)
+        self.gs = torch.zeros((n_layers + 1, batch, 64, channels), dtype=torch.bfloat16, device=dev)
+        self.masks = torch.zeros(L.bz_train_mask_bytes(channels, n_layers, batch), dtype=torch.uint8, device=dev)
+        nb = L.bz_train_wf_bytes(channels, n_layers)
+        self.wf_fwd = torch.zeros(nb, dtype=torch.uint8, device=dev)   # (the 2 taps of padding behind the stream stay zero)
+        self.wf_bwd = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        self.splits = L.bz_train_wgrad_splits(channels, n_layers, batch)
+        self.partial = torch.zeros((n_layers, 3, self.splits, 3, channels, channels), dtype=torch.float32, device=dev)
+        self.db_partial = torch.zeros((n_layers, self.splits, channels), dtype=torch.float32, device=dev)
+        self.zeros_c = torch.zeros(channels, dtype=torch.float32, device=dev)
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+
+class _TowerFn(torch.autograd.Function):
+    """x0 / the result / their gradients are [n, C, 8, 8] (nhwc=False: what a torch conv net passes around) or
+    [n, 64, C] (nhwc=True: the kernels' own layout -- no permute copies at either end)"""
+
+    @staticmethod
+    def forward(ctx, x0, W, b, plan, nhwc):
+        L, p = _lib.lib(), plan
+        n, C, Ly = p.n, p.C, p.L
+        assert x0.shape == ((n, 64, C) if nhwc else (n, C, 8, 8)), "input shape does not match the plan"
+        assert W.shape == (Ly, C, C, 3, 3) and b.shape == (Ly, C), "weight shapes do not match the plan"
+        Wc, bc = W.detach().contiguous().float(), b.detach().contiguous().float()
+        with torch.cuda.device(p.device):
+            p.acts[0].copy_(x0.detach() if nhwc else x0.detach().permute(0, 2, 3, 1).reshape(n, 64, C))
+            _lib.check(L.bz_train_pack_weights(Wc.data_ptr(), C, Ly, p.wf_fwd.data_ptr(), p.wf_bwd.data_ptr(), p._stream()))
+            _lib.check(L.bz_train_tower_fwd(p.acts[0].data_ptr(), p.wf_fwd.data_ptr(), bc.data_ptr(), C, Ly, n,
+                                            p.acts[1].data_ptr(), p.masks.data_ptr(), p._stream()))
+        ctx.plan, ctx.nhwc, ctx.in_dtype = p, nhwc, x0.dtype
+        y = p.acts[Ly]
+        return y.to(x0.dtype, copy=True) if nhwc else y.view(n, 8, 8, C).permute(0, 3, 1, 2).to(x0.dtype, copy=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        L, p = _lib.lib(), ctx.plan
+        n, C, Ly = p.n, p.C, p.L
+        with torch.cuda.device(p.device):
+            # g[L] = d loss / d (pre-activation of act[L]): the incoming gradient times the last layer's ReLU pattern
+            gyn = gy if ctx.nhwc else gy.permute(0, 2, 3, 1).reshape(n, 64, C)
+            torch.mul(gyn, p.acts[Ly] > 0, out=p.gs[Ly])
+            _lib.check(L.bz_train_tower_bwd(p.gs[Ly].data_ptr(), p.wf_bwd.data_ptr(), p.zeros_c.data_ptr(), p.masks.data_ptr(),
+                                            C, Ly, n, p.gs[0].data_ptr(), p._stream()))
+            _lib.check(L.bz_train_wgrad(p.acts[0].data_ptr(), p.gs[1].data_ptr(), C, Ly, n, p.splits, p.partial.data_ptr(),
+                                        p.db_partial.data_ptr(), p._stream()))
+        dW = p.partial.sum(2).permute(0, 4, 3, 1, 2).contiguous()   # [L, dy, dx, ci, co] -> torch's [L, co, ci, 3, 3]
+        db = p.db_partial.sum(1)
+        g0 = p.gs[0]
+        gx0 = g0.to(ctx.in_dtype, copy=True) if ctx.nhwc else g0.view(n, 8, 8, C).permute(0, 3, 1, 2).to(ctx.in_dtype, copy=True)
+        return gx0, dW, db, None, None
+
+
+class _RowsLinear(torch.autograd.Function):
+    """y = x @ W.T + b for x [rows, K] with MANY rows (batch x 64 cells) and small K / N (the stem: K = 32, the head
+    convolutions: N = 32).  The forward and d/dx are ordinary GEMMs; d/dW = dy.T @ x is a [N x rows] x [rows x K]
+    product whose long axis is the reduction: the BLAS picks a kernel without a K split for it (measured 174-239 us for
+    a 3 x 64 result), so it is done as a batched GEMM over 64 row chunks plus a sum (~10 us)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        # under autocast the product runs in bf16 (this Function is opaque to autocast, so it casts itself)
+        dt = torch.bfloat16 if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+        xb, Wb = x.to(dt), W.to(dt)
+        ctx.save_for_backward(xb, Wb)
+        ctx.dts = (x.dtype, W.dtype, b.dtype)
+        with torch.autocast("cuda", enabled=False):
+            return torch.addmm(b.to(dt), xb, Wb.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        gy = gy.to(x.dtype)
+        gx = (gy @ W).to(ctx.dts[0]) if ctx.needs_input_grad[0] else None
+        rows = x.shape[0]
+        ch = 64 if rows % 64 == 0 else 1
+        gW = torch.bmm(gy.view(ch, rows // ch, -1).transpose(1, 2), x.view(ch, rows // ch, -1)).sum(0, dtype=torch.float32)
+        gb = gy.sum(0, dtype=torch.float32)
+        return gx, gW.to(ctx.dts[1]), gb.to(ctx.dts[2])
+
+
+def rows_linear(x, W, b):
+    return _RowsLinear.apply(x, W, b)
+
+
+def tower_apply(x0, W, b, plan):
+    """x0 [n, C, 8, 8] (the stem's output after its ReLU) -> the tower's output [n, C, 8, 8]; differentiable in x0, W, b"""
+    return _TowerFn.apply(x0, W, b, plan, False)
+
+
+def tower_apply_nhwc(x0, W, b, plan):
+    """the same on [n, 64 cells, C] tensors -- the kernels' own layout (what PolicyValueNet's fused path passes)"""
+    return _TowerFn.apply(x0, W, b, plan, True)
+
+
+def tower_reference(x0, W, b, round_bf16=True, relu_masks=None):
+    """the same residual tower in plain torch (conv2d + relu + skip) -- the autograd reference of the GPU tests.
+    round_bf16: round every layer's output to bf16 (straight-through), as the kernels store it.  relu_masks: a list
+    of L boolean [n, C, 8, 8] tensors; layer l's ReLU then is "multiply by relu_masks[l]" -- with the kernels' own
+    patterns (act[l + 1] > 0) the reference takes the same branch of every ReLU as the kernels did."""
+    import torch.nn.functional as F
+    rnd = (lambda t: t + (t.bfloat16().float() - t).detach()) if round_bf16 else (lambda t: t)
+    act = (lambda z, l: F.relu(z)) if relu_masks is None else (lambda z, l: z * relu_masks[l])
+    a = x0
+    for blk in range(W.shape[0] // 2):
+        h = rnd(act(F.conv2d(a, W[2 * blk], b[2 * blk], padding=1), 2 * blk))
+        a = rnd(act(F.conv2d(h, W[2 * blk + 1], b[2 * blk + 1], padding=1) + a, 2 * blk + 1))
+    return a

@@ -328,6 +328,43 @@ int32_t bz_engine_reset_counters(bz_engine* e, void* stream);
 int32_t bz_engine_sum_counters(bz_engine* e, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* Training step of the residual tower: hand-written  */
+/* bf16 MFMA kernels for forward-with-saved-activations, backward-data and   */
+/* backward-weights of its n_layers = 2 NB conv3x3 layers.  The loop they    */
+/* serve has the shape of src/tic_tac_toe/SL/train.py:85-136 (forward, loss, */
+/* backward, Adam step); stem, heads, losses and the optimiser stay with the */
+/* caller (torch), as do the fp32 master weights.  C = 64 or 128.            */
+/*                                                                           */
+/* Tensors (device, bf16 unless noted), n = batch (a multiple of             */
+/* bz_train_positions_per_workgroup(C)):                                     */
+/*   act[a], a = 0..L : [n][64 cells][C]  act[0] = the stem's output (after   */
+/*                      its ReLU), act[a] = output of conv layer a - 1        */
+/*   g[a],   a = 0..L : [n][64][C]  g[a] = d loss / d (pre-activation of      */
+/*                      act[a]) for a >= 1; g[0] = d loss / d act[0]          */
+/*   W (fp32)         : [L][C co][C ci][3][3]  torch Conv2d layout, stacked   */
+/*   wf_fwd / wf_bwd  : bz_train_wf_bytes() each: the kernels' fragment-major */
+/*                      weight streams (bz_train_pack_weights writes both)    */
+/*   masks            : bz_train_mask_bytes(): the ReLU pattern of act[1..L]  */
+/* ------------------------------------------------------------------------ */
+int64_t bz_train_wf_bytes(int32_t C, int32_t n_layers);
+int32_t bz_train_positions_per_workgroup(int32_t C);
+int64_t bz_train_mask_bytes(int32_t C, int32_t n_layers, int32_t n);
+int32_t bz_train_pack_weights(const float* W, int32_t C, int32_t n_layers, void* wf_fwd, void* wf_bwd, void* stream);
+/* act0 = act[0]; acts_out = act[1..L] as [L][n][64][C]; bias fp32 [L][C] */
+int32_t bz_train_tower_fwd(const void* act0, const void* wf_fwd, const float* bias, int32_t C, int32_t n_layers, int32_t n,
+                           void* acts_out, void* masks, void* stream);
+/* g_top = g[L]; gs_out = g[0..L-1] as [L][n][64][C]; zeros_c = C fp32 zeros */
+int32_t bz_train_tower_bwd(const void* g_top, const void* wf_bwd, const float* zeros_c, const void* masks, int32_t C,
+                           int32_t n_layers, int32_t n, void* gs_out, void* stream);
+/* weight gradients: acts = act[0..L-1], gs = g[1..L], both [L][n][64][C].  partial (fp32) =
+ * [L][3 dy][splits][3 dx][C ci][C co] and db_partial (fp32) = [L][splits][C]: the caller sums over `splits`
+ * (bz_train_wgrad_splits()) and permutes the former to W's layout; the latter is the bias gradient (sum of
+ * g[l + 1] over positions and cells). */
+int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n);
+int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, int32_t n_layers, int32_t n, int32_t splits, float* partial,
+                       float* db_partial, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* In-library kernel timers: HIP events recorded on the launch stream around  */
 /* each launch of the named kernel (off by default; bench.py turns them on).  */
 /* ------------------------------------------------------------------------ */

@@ -52,12 +52,14 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--fp32-train", action="store_true", help="train without bf16 autocast (A/B of the loss curve)")
     ap.add_argument("--eager-train", action="store_true", help="launch every kernel of a training step by itself instead of replaying the captured HIP graph")
+    ap.add_argument("--miopen-train", action="store_true", help="train the tower through stock autograd (MIOpen) instead of the HIP training kernels (csrc/bz_train.hip)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
     torch.manual_seed(args.seed)
     gen = torch.Generator(device="cuda:0").manual_seed(args.seed)
-    module = PolicyValueNet(args.channels, args.blocks, 64)
+    kernels = not (args.miopen_train or args.eager_train or args.fp32_train or args.channels == 256)
+    module = PolicyValueNet(args.channels, args.blocks, 64, fused_tower=kernels)
     opt = make_optimizer(module, lr=args.lr) if args.eager_train else None
     graphed = None if args.eager_train else GraphedTrainStep(module, lr=args.lr, batch=args.batch, autocast=not args.fp32_train)
     bmax = max(args.games, args.arena_games)
