@@ -68,7 +68,7 @@ class GraphedTrainStep:
 
     The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
 
-    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None):
+    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None, lr_warmup_steps=0):
         # (NCHW on purpose: channels-last convolutions measured ~20 % faster per step in tools/bench_train.py, but the
         # closed loop then failed to learn the value head in one run and produced non-finite weights in two others --
         # profiles/r03_az_loop_channels_last_failure.txt -- so that layout is not offered)
@@ -83,13 +83,23 @@ class GraphedTrainStep:
             if not getattr(module, "fused_tower", False):
                 raise ValueError("tower_kernels=True needs PolicyValueNet(..., fused_tower=True)")
             self.plan = TowerPlan(module.C, 2 * module.NB, batch, device)
+        # lr_warmup_steps > 0: the learning rate ramps linearly from lr / warmup to lr over the first steps.  Adam's first
+        # updates move every weight by ~lr whatever the gradient's size; at the loop demo's lr = 2e-3 that kills the
+        # single-channel value head's ReLU (and in 2 of 4 seeds every head ReLU, i.e. the whole net) within the first
+        # 1-40 steps, in either memory layout -- profiles/r04_channels_last_cause.txt.  The rate lives in a device
+        # scalar (capturable Adam reads it inside the graph) that __call__ sets before each replay.
+        self.lr, self.warmup, self.steps_done = float(lr), int(lr_warmup_steps), 0
+        self.lr_t = torch.tensor(self._lr_at(0), dtype=torch.float32, device=self.dev)
         # (fused: the whole Adam update of all parameter tensors is one kernel instead of ~10 multi-tensor ones)
-        self.optimizer = torch.optim.Adam(module.parameters(), lr=lr, capturable=True, fused=True)
+        self.optimizer = torch.optim.Adam(module.parameters(), lr=self.lr_t, capturable=True, fused=True)
         self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.pi = torch.full((batch, na), 1.0 / na, dtype=torch.float32, device=self.dev)
         self.z = torch.zeros(batch, dtype=torch.int8, device=self.dev)
         self.graph, self.out = None, None
+
+    def _lr_at(self, k):
+        return self.lr * min(1.0, (k + 1) / self.warmup) if self.warmup > 0 else self.lr
 
     def _step(self):
         x = planes_from_bits(self.own, self.opp)
@@ -109,17 +119,13 @@ class GraphedTrainStep:
         placed in the static buffers, with lr scaled to 0 so that the weights do not move and the optimiser state zeroed
         afterwards; then the capture (which launches nothing: the first real step is the first replay)"""
         self.module.train()
-        lrs = [g["lr"] for g in self.optimizer.param_groups]
-        for g in self.optimizer.param_groups:
-            g["lr"] = 0.0
+        self.lr_t.zero_()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
             for _ in range(3):
                 self._step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        for g, lr in zip(self.optimizer.param_groups, lrs):
-            g["lr"] = lr
         for st in self.optimizer.state.values():  # the warm-up must not count as steps / leave moments behind
             for k, v in st.items():
                 if torch.is_tensor(v):
@@ -136,7 +142,9 @@ class GraphedTrainStep:
         torch.index_select(ex.z, 0, idx, out=self.z)
         if self.graph is None:
             self._capture()
+        self.lr_t.fill_(self._lr_at(self.steps_done))
         self.graph.replay()
+        self.steps_done += 1
         return self.out.clone()
 
 

@@ -106,8 +106,12 @@ class _RowsLinear(torch.autograd.Function):
         gx = (gy @ W).to(ctx.dts[0]) if ctx.needs_input_grad[0] else None
         rows = x.shape[0]
         ch = 64 if rows % 64 == 0 else 1
-        gW = torch.bmm(gy.view(ch, rows // ch, -1).transpose(1, 2), x.view(ch, rows // ch, -1)).sum(0, dtype=torch.float32)
-        gb = gy.sum(0, dtype=torch.float32)
+        gyc = gy.view(ch, rows // ch, -1).transpose(1, 2)
+        gW = torch.bmm(gyc, x.view(ch, rows // ch, -1)).sum(0, dtype=torch.float32)
+        # the bias gradient the same way (x a column of ones) rather than as gy.sum(0): a 65,536-row column sum is a
+        # multi-block torch reduction, and inside replayed HIP graphs such sums came back wrong once in a few hundred
+        # steps on this stack (all zeros here; 6e32 in the stock channels-last path -- profiles/r04_channels_last_cause.txt)
+        gb = torch.bmm(gyc, gy.new_ones((ch, rows // ch, 1))).sum(0, dtype=torch.float32).squeeze(1)
         return gx, gW.to(ctx.dts[1]), gb.to(ctx.dts[2])
 
 

@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--epochs", type=float, default=1.0, help="passes over the (augmented) window per iteration")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--lr-warmup", type=int, default=300, help="steps over which the learning rate ramps up (GraphedTrainStep.lr_warmup_steps): "
+                    "without it Adam's first steps at this lr can kill the head ReLUs -- profiles/r04_channels_last_cause.txt")
     ap.add_argument("--temp-moves", type=int, default=10)
     ap.add_argument("--arena-games", type=int, default=256)
     ap.add_argument("--arena-sims", type=int, default=64)
@@ -61,7 +63,7 @@ def main():
     kernels = not (args.miopen_train or args.eager_train or args.fp32_train or args.channels == 256)
     module = PolicyValueNet(args.channels, args.blocks, 64, fused_tower=kernels)
     opt = make_optimizer(module, lr=args.lr) if args.eager_train else None
-    graphed = None if args.eager_train else GraphedTrainStep(module, lr=args.lr, batch=args.batch, autocast=not args.fp32_train)
+    graphed = None if args.eager_train else GraphedTrainStep(module, lr=args.lr, batch=args.batch, autocast=not args.fp32_train, lr_warmup_steps=args.lr_warmup)
     bmax = max(args.games, args.arena_games)
     dnet = DeviceNet.from_module(module.round_to_bf16_(), bmax)
     lines = []
