@@ -42,6 +42,7 @@ struct bz_net {
     float *conv_w, *conv_b;          // [2NB][9][C][C] as [tap][ci][co]; [2NB][C]
     __bf16* conv_wf;                 // [2NB+pad][9][8][4][64][8] fragment-major (C == 128)
     __bf16 *stem_wf, *head_wf;       // [2][4][64][8], [8][64][8] fragments (C == 128)
+    __bf16 *conv_wf16, *stem_wf16;   // C == 128: the 16x16x32 path's fragments, [2NB+pad][9][4 kq][4 wt][2 a][64][8], [4 wt][2 a][64][8]
     uint8_t *conv_wf8, *head_wf8;    // e4m3: [L*9+1][2][4][2][64][16], [2][2][64][16]
     float *dq8, *head_dq8, *ones;    // [L][128], [4], [128]
     float *pol_w, *pol_b, *polfc_wT, *polfc_b;  // [2][C], [2], [128][65], [65]
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(192) k_heads(const InT* __restrict__ act, int 
 typedef Tw<64, 2> TwS64;     // latency shapes: the smallest P whose (M-tile, position) units fill 4 waves
 typedef Tw<128, 1> TwS128;
 typedef Tw<256, 1> TwS256;
+typedef Tw<128, 4, true> TwM16;  // the benchmark net's throughput shape on v_mfma_f32_16x16x32_bf16 (bz_tower.h)
 constexpr int kSmallBatch = 256;  // one workgroup per position and per CU up to here
 
 struct TowerArgs {
@@ -191,6 +193,7 @@ struct TowerArgs {
     const u32* n_dev;                // optional device-side count (<= n): workgroups beyond it exit at once
     int n, n_layers, VH;
     const uint4* wf;                 // tower weight fragments (see bz_net_create)
+    const uint4 *wf16, *stem_wf16;   // the same for the 16x16x32 path: [l][t][kq][wt][a][lane], [wt][a][lane]
     const float* bias;               // [n_layers][128]
     const uint4* stem_wf;            // [2][4][64] fragments of the stem as a K=32 GEMM (k = 2*tap + plane)
     const float* stem_b;             // [128]
@@ -227,6 +230,20 @@ __device__ __forceinline__ bf16x8 stem_frag(unsigned n_own, unsigned n_opp, int 
         const int bit = h ? b1 : b0;
         const unsigned o = (n_own >> bit) & 1u, p = (n_opp >> bit) & 1u;
         wd[j] = (o | (p << 16)) * 0x3F80u;  // bf16 1.0 in the low (own) / high (opp) half
+    }
+    uint4 u = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+// the same for the 16x16x32 MFMA: lane k-group g holds k = 8g .. 8g + 7, i.e. taps 4g .. 4g + 3 (own, opp)
+__device__ __forceinline__ bf16x8 stem_frag16(unsigned n_own, unsigned n_opp, int g) {
+    unsigned wd[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = 4 * g + j;                                   // tap; valid up to 8
+        const int bit = t <= 8 ? (t / 3) * 8 + t % 3 : 31;         // bit 31 of a neighbourhood word is always 0
+        const unsigned o = (n_own >> bit) & 1u, p = (n_opp >> bit) & 1u;
+        wd[j] = (o | (p << 16)) * 0x3F80u;
     }
     uint4 u = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     return __builtin_bit_cast(bf16x8, u);
@@ -270,19 +287,54 @@ k_tower_bf16(TowerArgs T) {
     const int wt0 = G::wt0(w), wp0 = G::pos0(w);
     // wave-uniform base (scalar registers) + lane: the loads take the SGPR-base addressing mode, so advancing the stream
     // costs scalar adds instead of 64-bit vector adds between the MFMAs
-    const uint4* ap = T.wf + (size_t)wt0 * 64;
-    WSets<G> WS;
+    const uint4* ap = G::M16 ? T.wf16 + (size_t)wt0 * 2 * 64 : T.wf + (size_t)wt0 * 64;
+    typename WSetsOf<G>::type WS;
+    if constexpr (G::M16) {  // tap 0 of the first layer: KQ steps x 2 channel halves
 #pragma unroll
-    for (int d = 0; d + 1 < G::DEPTH; ++d) {  // chunks 0 .. DEPTH - 2 of the first layer
+        for (int kq = 0; kq < G::KQ; ++kq)
 #pragma unroll
-        for (int kc = 0; kc < G::KS; ++kc)
+            for (int a = 0; a < 2; ++a) WS.s[0][kq][a] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kq * G::MT * 2 + a) * 64 + (unsigned)lane]));
+        ap += G::KQ * G::MT * 2 * 64;
+    } else {
 #pragma unroll
-            for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kc * G::MT + mt) * 64 + (unsigned)lane]));
-        ap += G::KS * G::MT * 64;
+        for (int d = 0; d + 1 < G::DEPTH; ++d) {  // chunks 0 .. DEPTH - 2 of the first layer
+#pragma unroll
+            for (int kc = 0; kc < G::KS; ++kc)
+#pragma unroll
+                for (int mt = 0; mt < MW; ++mt) WS.s[d][kc][mt] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kc * G::MT + mt) * 64 + (unsigned)lane]));
+            ap += G::KS * G::MT * 64;
+        }
     }
 
     // ---- stem: conv3x3 2 -> C as a [C x 32] x [32 x 64] GEMM per position
-    {
+    if constexpr (G::M16) {  // K = 32 is ONE 16x16x32 MFMA per quarter: lane (c, g) feeds cell c of half b with k = 8g ..
+        f32x16 acc[MW][G::NU];
+        Bias<G> bias;
+        const int c = lane & 15, g = lane >> 4;
+        load_bias16<G>(bias, T.stem_b, wt0, g);
+        bf16x8 sa[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) sa[a] = __builtin_bit_cast(bf16x8, T.stem_wf16[(wt0 * 2 + a) * 64 + lane]);
+        u64 own[2], opp[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            int pos = pos0 + wp0 + 2 * b + (c >> 3);
+            pos = pos < T.n ? pos : T.n - 1;
+            own[b] = T.own[pos]; opp[b] = T.opp[pos];
+        }
+#pragma unroll
+        for (int u = 0; u < G::NU; ++u) {
+            acc[0][u] = (f32x16)(0.0f);
+            const int cell = 8 * u + (c & 7);
+            const bf16x8 f0 = stem_frag16(nbhd(own[0], cell), nbhd(opp[0], cell), g);
+            const bf16x8 f1 = stem_frag16(nbhd(own[1], cell), nbhd(opp[1], cell), g);
+            mfma16_quarter<0>(acc[0][u], sa[0], f0);
+            mfma16_quarter<1>(acc[0][u], sa[0], f1);
+            mfma16_quarter<2>(acc[0][u], sa[1], f0);
+            mfma16_quarter<3>(acc[0][u], sa[1], f1);
+        }
+        epilogue16<G>(acc, bufX + wp0 * G::TILE, false, bias, wt0, lane);
+    } else {
         f32x16 acc[MW][G::NU];
         Bias<G> bias;
         load_bias<G>(bias, T.stem_b, wt0, h);
@@ -704,7 +756,7 @@ struct Carver {
     int64_t take(int64_t bytes) { int64_t o = off; off += (bytes + 255) & ~int64_t(255); return o; }
 };
 struct NetOffsets {
-    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf8, head_wf8, dq8, head_dq8, ones, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
+    int64_t stem_w, stem_b, conv_w, conv_b, conv_wf, stem_wf, head_wf, conv_wf16, stem_wf16, conv_wf8, head_wf8, dq8, head_dq8, ones, pol_w, pol_b, polfc_wT, polfc_b, val_w, val_b, v1_wT, v1_b, v2_w,
         v2_b, act_a, act_b, total;
 };
 NetOffsets net_carve(int C, int NB, int VH, int mb) {
@@ -717,6 +769,8 @@ NetOffsets net_carve(int C, int NB, int VH, int mb) {
     const int64_t KC = C / 16, MT = C / 32;             // k-steps per tap, M-tiles (1-KB fragments: [kc][mt][64 lanes][8])
     o.conv_wf = k.take(mfma ? (L * 9 + 2) * KC * MT * 1024 : 0);  // + 2 taps: the prefetch runs up to two chunks past the end
     o.stem_wf = k.take(mfma ? 2 * MT * 1024 : 0); o.head_wf = k.take(mfma ? KC * 1024 : 0);
+    o.conv_wf16 = k.take(C == kTC ? (L * 9 + 2) * (C / 32) * MT * 2 * 1024 : 0);  // (+ 2 taps: prefetch past the end)
+    o.stem_wf16 = k.take(C == kTC ? MT * 2 * 1024 : 0);
     o.conv_wf8 = k.take(C == kTC ? (L * 9 + 1) * 2LL * 4 * 2 * 64 * 16 : 0); o.head_wf8 = k.take(2 * 2 * 64 * 16);
     o.dq8 = k.take((L + 1) * 128 * 4); o.head_dq8 = k.take(16); o.ones = k.take(128 * 4);
     o.pol_w = k.take(2LL * C * 4); o.pol_b = k.take(8); o.polfc_wT = k.take(128 * 65 * 4); o.polfc_b = k.take(65 * 4);
@@ -790,6 +844,17 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                         sf[(((size_t)kc * MT + mt) * 64 + ln) * 8 + j] = f2bf(v);
                     }
     }
+    if (C == kTC) {  // 16x16x32 path: A[co = 32wt + 16a + (lane & 15)][k = 8 (lane >> 4) + j]
+        uint16_t* sf = reinterpret_cast<uint16_t*>(img.data() + o.stem_wf16);
+        for (int wt = 0; wt < MT; ++wt)
+            for (int a = 0; a < 2; ++a)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int j = 0; j < 8; ++j) {
+                        int co = 32 * wt + 16 * a + (ln & 15), k = 8 * (ln >> 4) + j;
+                        float v = k < 18 ? q[(co * 2 + (k & 1)) * 9 + (k >> 1)] : 0.0f;
+                        sf[(((size_t)wt * 2 + a) * 64 + ln) * 8 + j] = f2bf(v);
+                    }
+    }
     q += (size_t)C * 18;
     for (int i = 0; i < C; ++i) F(o.stem_b)[i] = q[i];
     q += C;
@@ -805,6 +870,12 @@ static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
                         int kc = ci >> 4, hh = (ci >> 3) & 1, j = ci & 7, mt = co >> 5, rr = co & 31;
                         size_t f = ((((size_t)l * 9 + t) * KC + kc) * MT + mt) * 64 + (hh * 32 + rr);
                         wf[f * 8 + j] = f2bf(v);
+                    }
+                    if (C == kTC) {  // 16x16x32 path: [l][t][kq][wt][a][lane = 16g + c][j]: co = 32wt + 16a + c, ci = 32kq + 8g + j
+                        uint16_t* w16 = reinterpret_cast<uint16_t*>(img.data() + o.conv_wf16);
+                        int kq = ci >> 5, g = (ci >> 3) & 3, j = ci & 7, wt = co >> 5, a = (co >> 4) & 1, c = co & 15;
+                        size_t f = (((((size_t)l * 9 + t) * (C / 32) + kq) * MT + wt) * 2 + a) * 64 + (g * 16 + c);
+                        w16[f * 8 + j] = f2bf(v);
                     }
                 }
         q += (size_t)C * C * 9;
@@ -910,6 +981,7 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
     n->conv_w = at<float>(ws, o.conv_w); n->conv_b = at<float>(ws, o.conv_b);
     n->conv_wf = (C == 64 || C == 128 || C == 256) ? at<__bf16>(ws, o.conv_wf) : nullptr;
     n->stem_wf = at<__bf16>(ws, o.stem_wf); n->head_wf = at<__bf16>(ws, o.head_wf);
+    n->conv_wf16 = C == kTC ? at<__bf16>(ws, o.conv_wf16) : nullptr; n->stem_wf16 = C == kTC ? at<__bf16>(ws, o.stem_wf16) : nullptr;
     n->conv_wf8 = C == kTC ? at<uint8_t>(ws, o.conv_wf8) : nullptr; n->head_wf8 = at<uint8_t>(ws, o.head_wf8);
     n->dq8 = at<float>(ws, o.dq8); n->head_dq8 = at<float>(ws, o.head_dq8); n->ones = at<float>(ws, o.ones);
     n->pol_w = at<float>(ws, o.pol_w); n->pol_b = at<float>(ws, o.pol_b);
@@ -930,7 +1002,7 @@ BZ_EXPORT int32_t bz_net_create(int32_t C, int32_t NB, int32_t VH, int32_t max_b
         hipError_t e3 = hipSuccess;
 #define BZ_TOWER_LDS(GEOM) hipFuncSetAttribute(reinterpret_cast<const void*>(k_tower_bf16<GEOM>), hipFuncAttributeMaxDynamicSharedMemorySize, GEOM::LDS)
         if (C == 64) { e3 = BZ_TOWER_LDS(Tw<64>); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS64); }
-        if (C == 128) { e3 = BZ_TOWER_LDS(Tw<128>); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS128); }
+        if (C == 128) { e3 = BZ_TOWER_LDS(TwM16); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS128); }
         if (C == 256) { e3 = BZ_TOWER_LDS(Tw<256>); if (e3 == hipSuccess) e3 = BZ_TOWER_LDS(TwS256); }  // TwS256: 73 KB
 #undef BZ_TOWER_LDS
         if (e3 != hipSuccess) { delete n; return hip_fail(e3, "hipFuncSetAttribute(k_tower_bf16)"); }
@@ -1008,6 +1080,7 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     T.own = own; T.opp = opp; T.n_dev = n_dev; T.n = cnt; T.n_layers = 2 * n->NB; T.VH = n->VH;
     T.wf = reinterpret_cast<const uint4*>(n->conv_wf); T.bias = n->conv_b;
     T.stem_wf = reinterpret_cast<const uint4*>(n->stem_wf); T.stem_b = n->stem_b;
+    T.wf16 = reinterpret_cast<const uint4*>(n->conv_wf16); T.stem_wf16 = reinterpret_cast<const uint4*>(n->stem_wf16);
     T.head_wf = reinterpret_cast<const uint4*>(n->head_wf); T.pol_b = n->pol_b; T.val_b = n->val_b;
     T.wf8 = reinterpret_cast<const uint4*>(n->conv_wf8); T.head_wf8 = reinterpret_cast<const uint4*>(n->head_wf8);
     T.dq8 = n->dq8; T.head_dq8 = n->head_dq8; T.ones = n->ones;
@@ -1022,7 +1095,7 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
 #define BZ_TOWER_LAUNCH(GEOM) hipLaunchKernelGGL(k_tower_bf16<GEOM>, dim3((cnt + GEOM::P - 1) / GEOM::P), dim3(256), GEOM::LDS, s, T)
             if (n->C == 64) { if (small) BZ_TOWER_LAUNCH(TwS64); else BZ_TOWER_LAUNCH(Tw<64>); }
             else if (n->C == 256) { if (small) BZ_TOWER_LAUNCH(TwS256); else BZ_TOWER_LAUNCH(Tw<256>); }
-            else { if (small) BZ_TOWER_LAUNCH(TwS128); else BZ_TOWER_LAUNCH(Tw<128>); }
+            else { if (small) BZ_TOWER_LAUNCH(TwS128); else BZ_TOWER_LAUNCH(TwM16); }
 #undef BZ_TOWER_LAUNCH
         }
     }

@@ -44,9 +44,13 @@ constexpr int kTC = 128;                  // channels of the benchmark net (the 
 // skip them, position-major units point the affected lanes at a zero cell.
 // (Round 1 measured 2 positions x 2 workgroups per CU, a tile-major last tap and the 16x16x32 MFMA shape, round 2 the
 // MW = 2 split at C = 128: all within +-1 % because the kernel sits on the power-limited clock -- DESIGN.md 5.)
-template <int C_, int P_ = 512 / C_> struct Tw {
+template <int C_, int P_ = 512 / C_, bool M16_ = false> struct Tw {
     static_assert(C_ == 64 || C_ == 128 || C_ == 256, "the MFMA tower is built for 64, 128 or 256 channels");
     static constexpr int C = C_;
+    // M16: the K-loop on v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (the "16x16x32 path" at the end of this file):
+    // the same LDS image, the same bytes per MAC from LDS and L2, the same cycles -- and a higher clock under load
+    static constexpr bool M16 = M16_;
+    static constexpr int KQ = C / 32;                  // M16: steps of 32 input channels per conv tap
     static constexpr int KC = C / 16;                  // k-steps (16 input channels) per conv tap
     static constexpr int MT = C / 32;                  // M-tiles (32 output channels)
     static constexpr int CELL = 2 * C;                 // bytes of one board cell (all channels, bf16)
@@ -115,7 +119,7 @@ template <int C_, int P_ = 512 / C_> struct Tw {
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
-#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER)) && !defined(BZ_EXPERIMENT)
+#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER) || defined(BZ_EXP_MFMA16)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
 // weight-fragment loads of the bf16 tower.  Diagnostic option BZ_EXP_WEIGHTS_NT: non-temporal loads, to see whether the
@@ -176,14 +180,33 @@ __device__ __forceinline__ void load_b(bf16x8 (&b)[G::NU], const char* in, const
     }
 }
 template <class G, int TAP>
-__device__ __forceinline__ void mfma_units(f32x16 (&acc)[G::MW][G::NU], const bf16x8 (&a)[G::MW], const bf16x8 (&b)[G::NU]) {
+__device__ __forceinline__ void mfma_units(f32x16 (&acc)[G::MW][G::NU], const bf16x8 (&a)[G::MW], const bf16x8 (&b)[G::NU],
+                                           [[maybe_unused]] int kpar = 0) {
     constexpr int dy = TAP / 3 - 1;
 #pragma unroll
     for (int mt = 0; mt < G::MW; ++mt)
 #pragma unroll
         for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u)
         {
+#ifdef BZ_EXP_MFMA16
+            // TIMING ONLY (the results are wrong): the same operand registers, LDS and weight traffic, but the matrix
+            // work of a 32x32x16 MFMA issued as TWO v_mfma_f32_16x16x32_bf16 (same MACs, 2 x 16 cycles instead of 32),
+            // accumulating into the quarters of the same 16 registers (even k-steps: quarters 0, 1; odd: 2, 3) -- what a
+            // kernel built on the 16x16x32 shape with a 32 co x (2 x 16 cells) wave tile would issue per 1-KB weight
+            // fragment.  tools/exp_ab_mfma16.sh: does the chip hold a higher clock on that shape (MI355X_MICROARCH.md,
+            // DVFS item 7)?
+            {
+                f32x16& c = acc[mt][u];
+                f32x4 q0 = kpar ? f32x4{c[8], c[9], c[10], c[11]} : f32x4{c[0], c[1], c[2], c[3]};
+                f32x4 q1 = kpar ? f32x4{c[12], c[13], c[14], c[15]} : f32x4{c[4], c[5], c[6], c[7]};
+                q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[u], q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a[mt], q1, 0, 0, 0);  // (operands swapped: the compiler merges two identical products into one)
+                if (kpar) { c[8] = q0[0]; c[9] = q0[1]; c[10] = q0[2]; c[11] = q0[3]; c[12] = q1[0]; c[13] = q1[1]; c[14] = q1[2]; c[15] = q1[3]; }
+                else { c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3]; c[4] = q1[0]; c[5] = q1[1]; c[6] = q1[2]; c[7] = q1[3]; }
+            }
+#else
             acc[mt][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[u], acc[mt][u], 0, 0, 0);
+#endif
 #ifdef BZ_EXP_NOPS  // diagnostic duty sweep (tools/exp_duty_sweep.sh): BZ_EXP_NOPS x 8 idle issue cycles behind every MFMA
 #pragma unroll
             for (int z = 0; z < BZ_EXP_NOPS; ++z) asm volatile("s_nop 7");
@@ -225,7 +248,7 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::NU], WSets<G>
     for (int k = 0; k < G::KS; ++k) {
         if (k + D < G::KS) load_b<G, TAP>(B[(base + k + D) % NB], in, boff, kc0 + k + D);
         else if constexpr (!last) load_b<G, TAP_N>(B[(base + k + D) % NB], in, boff_n, kc0_n + k + D - G::KS);  // next chunk
-        mfma_units<G, TAP>(acc, use[k], B[(base + k) % NB]);
+        mfma_units<G, TAP>(acc, use[k], B[(base + k) % NB], k & 1);
     }
     constexpr int NA = G::unit_hi(TAP / 3 - 1) - G::unit_lo(TAP / 3 - 1);
 #pragma unroll
@@ -233,7 +256,11 @@ __device__ __forceinline__ void chunk_step(f32x16 (&acc)[G::MW][G::NU], WSets<G>
         if (G::MW == 1) {
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
+#ifdef BZ_EXP_MFMA16
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // the unit's 2 half-size MFMAs
+#else
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
@@ -364,17 +391,157 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out,
     }
 }
 
+// ------------------------------------------------------------------ the 16x16x32 path (Tw<C, P, true>)
+// Same wave tile as the 32x32x16 path -- 32 output channels x the 8 board rows of 4 positions -- cut into 16 x 16 pieces:
+// a unit's accumulator f32x16 holds four 16 x 16 tiles, quarter 2a + b = output channels 32 wt + 16 a .. + 15 of the
+// unit's cells 16 b .. 16 b + 15 (positions 2 b and 2 b + 1 of the row).  Lane (c = lane & 15, g = lane >> 4):
+//   A (weights)     : row co = 16 a + c, k = 8 g + j  -> one 1-KB fragment per (32 input channels, a)
+//   B (activations) : k = 8 g + j of cell c of half b -> ds_read_b128 of chunk 4 kq + g of that cell
+//   D quarter (a, b): channel 16 a + 4 g + i (i = register), cell 16 b + c
+// A "sub-step" (kq, b) = 32 input channels x one half of every unit: 8 ds_read_b128 + 16 MFMAs (2 per unit: a = 0, 1),
+// i.e. the (2 MFMA, 1 DS read) pattern; a tap is 2 KQ sub-steps and 2 KQ weight fragments -- the bytes per MAC from LDS
+// and from L2 are those of the 32x32x16 path, and so are the cycles (an MFMA of this shape is 16 cycles for half the
+// MACs).  What changes is the clock the chip holds: MI355X_MICROARCH.md (DVFS give-back, item 7) reports 1.12-1.15 x the
+// FLOP/s for this shape at equal cycles; measured on this kernel 1.86 -> 2.00 GHz (profiles/r04_ab_tower_16x16.txt).
+// The LDS image and its swizzle are unchanged: with chunk = 4 kq + g the 16 lanes of every ds_read_b128 lane group
+// ({0-3, 12-15, 20-27}, ...) still hit 16 distinct 16-byte slots for every tap (g differs by 1 exactly where the
+// (position, column) sets of the group's two halves are disjoint under XOR 1).
+template <class G> struct WSets16 { bf16x8 s[2][G::KQ][2]; };  // two register sets x KQ steps x 2 channel halves
+
+template <class G, int TAP>
+__device__ __forceinline__ int tap_off16(int c, int g) {  // lane's B offset for sub-step (kq = 0, b = 0) of tap TAP, row 0
+    constexpr int dx = TAP % 3 - 1;
+    const int xx = (c & 7) + dx;
+    return (c >> 3) * G::TILE + G::cell_at(0, xx) + ((G::sw(c >> 3, xx) ^ g) << 4);
+}
+template <class G, int TAP>
+__device__ __forceinline__ void load_b16(bf16x8 (&b)[G::NU], const char* in, int boff, int kq, int half) {
+    constexpr int dy = TAP / 3 - 1;
+#pragma unroll
+    for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u)
+        b[u] = *reinterpret_cast<const bf16x8*>(in + (boff ^ (kq << 6)) + half * 2 * G::TILE + G::unit_imm(u) + dy * G::ROWC * G::CELL);
+}
+template <int Q>
+__device__ __forceinline__ void mfma16_quarter(f32x16& c, const bf16x8& a, const bf16x8& b) {
+    f32x4 q = {c[4 * Q], c[4 * Q + 1], c[4 * Q + 2], c[4 * Q + 3]};
+    q = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q, 0, 0, 0);
+    c[4 * Q] = q[0]; c[4 * Q + 1] = q[1]; c[4 * Q + 2] = q[2]; c[4 * Q + 3] = q[3];
+}
+template <class G, int TAP, int HALF>
+__device__ __forceinline__ void mfma_units16(f32x16 (&acc)[G::MW][G::NU], const bf16x8 (&a)[2], const bf16x8 (&b)[G::NU]) {
+    constexpr int dy = TAP / 3 - 1;
+#pragma unroll
+    for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u) {
+        mfma16_quarter<HALF>(acc[0][u], a[0], b[u]);      // a = 0: quarter b
+        mfma16_quarter<2 + HALF>(acc[0][u], a[1], b[u]);  // a = 1: quarter 2 + b
+    }
+}
+// one conv tap: 2 KQ sub-steps; the register set freed by the previous tap is filled for the next one
+template <int S, int TAP, class G>
+__device__ __forceinline__ void tap_step16(f32x16 (&acc)[G::MW][G::NU], WSets16<G>& WS, const uint4*& ap, const char* in, int& boff,
+                                           int lane, bf16x8 (&B)[2][G::NU]) {
+    constexpr bool last = TAP == 8;
+    constexpr int TAP_N = last ? TAP : TAP + 1;
+    bf16x8 (&use)[G::KQ][2] = WS.s[S];
+    bf16x8 (&nxt)[G::KQ][2] = WS.s[S ^ 1];
+#pragma unroll
+    for (int kq = 0; kq < G::KQ; ++kq)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) nxt[kq][a] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kq * G::MT * 2 + a) * 64 + (unsigned)lane]));
+    ap += G::KQ * G::MT * 2 * 64;
+    int boff_n = boff;
+    if constexpr (TAP_N % 3 != TAP % 3) boff_n = tap_off16<G, TAP_N>(lane & 15, lane >> 4);
+    constexpr int NS = 2 * G::KQ;  // sub-steps; sub-step ss sits in buffer ss & 1 (NS is even: every tap starts in buffer 0)
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+        if (ss + 1 < NS) load_b16<G, TAP>(B[(ss + 1) & 1], in, boff, (ss + 1) >> 1, (ss + 1) & 1);
+        else if constexpr (!last) load_b16<G, TAP_N>(B[0], in, boff_n, 0, 0);  // first sub-step of the next tap
+        if (ss & 1) mfma_units16<G, TAP, 1>(acc, use[ss >> 1], B[1]);
+        else mfma_units16<G, TAP, 0>(acc, use[ss >> 1], B[0]);
+    }
+    constexpr int NA = G::unit_hi(TAP / 3 - 1) - G::unit_lo(TAP / 3 - 1);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // the unit's 2 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
+    }
+    boff = boff_n;
+    __builtin_amdgcn_sched_barrier(0);  // one tap per scheduling region
+}
+template <int S0, int TAP, class G>
+__device__ __forceinline__ void run_taps16(f32x16 (&acc)[G::MW][G::NU], WSets16<G>& WS, const uint4*& ap, const char* in, int& boff,
+                                           int lane, bf16x8 (&B)[2][G::NU]) {
+    if constexpr (TAP < 9) {
+        tap_step16<(S0 + TAP) & 1, TAP, G>(acc, WS, ap, in, boff, lane, B);
+        run_taps16<S0, TAP + 1, G>(acc, WS, ap, in, boff, lane, B);
+    }
+}
+// the layer's biases for the lane's channels 16 a + 4 g + i (kept in Bias<G>::q[0][a])
+template <class G>
+__device__ __forceinline__ void load_bias16(Bias<G>& b, const float* __restrict__ bl, int wt, int g) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) b.q[0][a] = *reinterpret_cast<const f32x4*>(bl + 32 * wt + 16 * a + 4 * g);
+    b.q[0][2] = b.q[0][3] = (f32x4)(0.0f);
+}
+// +bias (+skip) -> ReLU -> bf16 -> LDS for the 16x16 quarters.  `out` points at the wave's first position.
+template <class G>
+__device__ __forceinline__ void epilogue16(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt,
+                                           int lane) {
+    const int c = lane & 15, g = lane >> 4, x = c & 7, pl = c >> 3;
+    const int swz = G::sw(pl, x);
+    // per-lane bases of unit 0 / unit 1 (even / odd rows) of the lane's position in half b = 0; + 8 (g & 1): the lane's 4
+    // channels are the lower or upper half of a 16-byte chunk
+    int home2[2] = {pl * G::TILE + G::cell_at(0, x) + 8 * (g & 1), pl * G::TILE + G::cell_at(1, x) + 8 * (g & 1)};
+    asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int slot = ((4 * wt + 2 * a + (g >> 1)) ^ swz) << 4;
+        const f32x4 bq = bias.q[0][a];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int u = par; u < G::NU; u += 2) {
+                    const int off = home2[par] + slot + b * 2 * G::TILE + (u & ~1) * G::ROWC * G::CELL;
+                    const int q = 2 * a + b;
+                    f32x4 v = {acc[0][u][4 * q], acc[0][u][4 * q + 1], acc[0][u][4 * q + 2], acc[0][u][4 * q + 3]};
+                    v = v + bq;
+                    if (second) {
+                        bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+                        v = v + __builtin_convertvector(sk, f32x4);
+                    }
+                    f32x2 vlo = {v[0], v[1]}, vhi = {v[2], v[3]};
+                    s16x2 lo = __builtin_bit_cast(s16x2, __builtin_convertvector(vlo, bf16x2));
+                    s16x2 hi = __builtin_bit_cast(s16x2, __builtin_convertvector(vhi, bf16x2));
+                    lo = __builtin_elementwise_max(lo, (s16x2)(0));
+                    hi = __builtin_elementwise_max(hi, (s16x2)(0));
+                    *reinterpret_cast<uint2*>(out + off) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+                }
+    }
+}
+
 // One conv3x3 layer over the resident positions: LDS -> MFMA -> (+bias, +skip, ReLU) -> LDS.
 // S0 = register set that holds chunk 0's weight fragments on entry; on exit it is set (S0 + NCH) % DEPTH.
 // What happens to a layer's accumulators is a policy: EpInfer = the inference epilogue above; the training kernels
 // (bz_train.hip) bring their own (ReLU masks out / masks in).  ep(acc, out, second, bias, wt0, r, h).
 template <class G> struct EpInfer {
     __device__ __forceinline__ void operator()(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt0,
-                                               int r, int h) const { epilogue<G>(acc, out, second, bias, wt0, r, h); }
+                                               int r, int h) const {
+        if constexpr (G::M16) epilogue16<G>(acc, out, second, bias, wt0, 32 * h + r);
+        else epilogue<G>(acc, out, second, bias, wt0, r, h);
+    }
 };
+// the weight-fragment register sets of a geometry
+template <class G> struct WSetsOf { typedef WSets<G> type; };
+template <int C_, int P_> struct WSetsOf<Tw<C_, P_, true>> { typedef WSets16<Tw<C_, P_, true>> type; };
 template <int S0, class G, class EP = EpInfer<G>>
 __device__ __forceinline__ void conv_layer(const char* in, char* out, bool second, const float* __restrict__ bl,
-                                           WSets<G>& WS, const uint4*& ap, int w, int r, int h,
+                                           typename WSetsOf<G>::type& WS, const uint4*& ap, int w, int r, int h,
                                            unsigned long long (&tacc)[4], const EP& ep = EP()) {
     [[maybe_unused]] unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     BZ_STAMP(t0);
@@ -386,9 +553,19 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
     const int wpos = G::pos0(w) * G::TILE;
     in += wpos; out += wpos;
     Bias<G> bias;
-    load_bias<G>(bias, bl, G::wt0(w), h);
+    if constexpr (G::M16) load_bias16<G>(bias, bl, G::wt0(w), (32 * h + r) >> 4);
+    else load_bias<G>(bias, bl, G::wt0(w), h);
     int boff[2];
-    if constexpr (G::ROWT) {
+    if constexpr (G::M16) {
+        static_assert(G::ROWT && G::MW == 1 && G::C == 128, "the 16x16x32 path serves the row-tile shape of the 128-channel net");
+        bf16x8 B[2][G::NU];
+        const int lane = 32 * h + r;
+        boff[0] = tap_off16<G, 0>(lane & 15, lane >> 4);
+        boff[1] = 0;
+        load_b16<G, 0>(B[0], in, boff[0], 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        run_taps16<S0, 0, G>(acc, WS, ap, in, boff[0], lane, B);
+    } else if constexpr (G::ROWT) {
         bf16x8 B[G::NBUF][G::NU];
         tap_off<G, 0>(r, h, boff);
 #pragma unroll

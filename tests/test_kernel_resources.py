@@ -52,7 +52,7 @@ def test_tree_kernels_stay_within_their_register_budget(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def test_net_kernels_do_not_spill(tmp_path):
     res = _resources("bz_net.hip", tmp_path)
-    for parts in (("k_tower_bf16", "Li128ELi4E"), ("k_tower_bf16", "Li64ELi8E"), ("k_tower_bf16", "Li256ELi2E"),
+    for parts in (("k_tower_bf16", "Li128ELi4ELb1E"), ("k_tower_bf16", "Li64ELi8E"), ("k_tower_bf16", "Li256ELi2E"),
                   ("k_tower_bf16", "Li128ELi1E"), ("k_tower_fp8",)):
         k = _find(res, *parts)
         assert k["vspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
@@ -75,5 +75,22 @@ def test_towers_skip_the_padding_row_mfmas(tmp_path):
     + stem + heads: a regression to position-major units would show up here as 1184 / 292."""
     _resources("bz_net.hip", tmp_path)
     asm = _resources.asm
-    assert _count(asm, ("k_tower_bf16", "Li128ELi4E"), "v_mfma_f32_32x32x16_bf16") == 2 * 528 + 16 + 16
+    # round 4: the benchmark net's throughput shape runs on v_mfma_f32_16x16x32_bf16 (half the MACs each): 2 x 528 per
+    # layer body, 2 x 16 for the stem (4 quarters x 8 units); the heads stay on 32x32x16 (16)
+    assert _count(asm, ("k_tower_bf16", "Li128ELi4ELb1E"), "v_mfma_f32_16x16x32_bf16") == 2 * (2 * 528) + 32
+    assert _count(asm, ("k_tower_bf16", "Li128ELi4ELb1E"), "v_mfma_f32_32x32x16_bf16") == 16
+    assert _count(asm, ("k_tower_bf16", "Li64ELi8ELb0E"), "v_mfma_f32_32x32x16_bf16") == 2 * 264 + 8 + 16  # C = 64: 4 k-steps per tap
     assert _count(asm, ("k_tower_fp8",), "v_mfma_scale_f32_32x32x64_f8f6f4") == 2 * 132 + 4
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_training_kernels_do_not_spill(tmp_path):
+    """csrc/bz_train.hip: forward / backward-data keep the inference tower's budget (one workgroup per CU), the
+    weight-gradient kernel keeps its staging registers in registers (an array of HIP's uint4 STRUCT had put them into
+    scratch memory: 272 bytes per lane) and really reads both operands through the LDS transpose read"""
+    res = _resources("bz_train.hip", tmp_path)
+    for parts in (("k_train_fwd", "Li64ELi8E"), ("k_train_fwd", "Li128ELi4E"), ("k_train_bwd", "Li64ELi8E"), ("k_train_bwd", "Li128ELi4E"),
+                  ("k_train_wgrad", "Li64E"), ("k_train_wgrad", "Li128E")):
+        k = _find(res, *parts)
+        assert k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
+    assert _count(_resources.asm, ("k_train_wgrad", "Li128E"), "ds_read_b64_tr_b16") >= 14

@@ -1,0 +1,16 @@
+#!/bin/bash
+# does the bf16 tower gain from the 16x16x32 MFMA shape at the power wall?  TIMING-ONLY variant
+# (-DBZ_EXP_MFMA16: every 32x32x16 MFMA issued as two 16x16x32 on the same operand registers -- same MACs, same LDS and
+# weight traffic, same 8 MFMAs' worth of flops per 1-KB weight fragment; the results are wrong) against the product
+# kernel, interleaved on ONE device, plus the in-kernel clock of both from the stamped builds.  Run through gpurun.
+set -e
+cd "$(dirname "$0")/.."
+SO=$(python -c "from betazero_amd import build; print(build.build_variant('mfma16', ['-DBZ_EXP_MFMA16']))")
+ST=$(python -c "from betazero_amd import build; print(build.build_variant('stamps', ['-DBZ_EXP_STAMPS']))")
+ST16=$(python -c "from betazero_amd import build; print(build.build_variant('stampsmfma16', ['-DBZ_EXP_STAMPS', '-DBZ_EXP_MFMA16']))")
+for i in 1 2 3; do
+  echo "== product (v_mfma_f32_32x32x16_bf16)"; python tools/bench_net.py 4096 1000 | grep -E "forward|tower"
+  echo "== timing-only 2 x v_mfma_f32_16x16x32_bf16 per unit"; BZ_HIP_SO="$SO" BZ_ALLOW_EXPERIMENT=1 python tools/bench_net.py 4096 1000 | grep -E "forward|tower"
+done
+echo "== stamps, product shape"; BZ_HIP_SO="$ST" BZ_ALLOW_EXPERIMENT=1 python tools/exp_stamps.py
+echo "== stamps, 16x16x32 timing-only"; BZ_HIP_SO="$ST16" BZ_ALLOW_EXPERIMENT=1 python tools/exp_stamps.py
