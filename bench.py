@@ -44,13 +44,29 @@ MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICRO
 HBM_PEAK_GBS = 8000.0
 PLIES_PER_GAME = 58                                   # searched moves per cfg-3 game (60 - 2 opening plies)
 WHOLE_GAME_SIMS = 32                                  # cpu_baseline.whole_game: complete games on the C port at this many sims/move
-PMC_TRAFFIC = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+PMC_TRAFFIC = ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
 
 
 def tree_bytes(c):
     """SURVEY.md 8(d) algorithmic bytes from the kernels' exact work counters"""
     return (32 * c["n_path_nodes"] + 12 * c["n_child_scored"] + 16 * c["n_edges_backed"] + 32 * c["n_expanded"] +
             13 * c["n_child_written"] + 264 * c["n_net_leaves"] + 42 * c["n_env_steps"])
+
+
+
+def pmc_traffic(key, **shape):
+    """(hbm bytes per launch, source note) of a kernel from the committed counter passes (tools/profile_round.sh ->
+    tools/make_traffic_json.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 fetch correction
+    applied) -- PMC counters cannot run inside a timed process, so the line carries the figure measured on the same
+    command, and only when the entry's recorded shape equals this run's (`shape`); (None, None) otherwise."""
+    for path in PMC_TRAFFIC:
+        try:
+            ent = json.load(open(os.path.join(ROOT, path)))[key]
+        except Exception:
+            continue
+        if all(ent.get(k) == v for k, v in shape.items()):
+            return ent["hbm_bytes_per_launch"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{ent.get('command', '?')}` ({path})"
+    return None, None
 
 
 _T0 = time.time()
@@ -391,13 +407,14 @@ def run_net(ctx, B, K, W, fp8):
     peak = 2 * MFMA_PEAK_TFLOPS if fp8 else MFMA_PEAK_TFLOPS
     ach = B * NET_FLOP_PER_POS / (avg_ms * 1e-3) / 1e12
     prec = "fp8" if fp8 else "bf16"
+    tr, tr_src = pmc_traffic("k_tower_fp8@8192" if fp8 else "k_tower_bf16@4096", positions_per_launch=B)
     return {"metric": "net_leaf_evals_per_s", "value": B * K * ctx.world / dt, "unit": "evals/s", "n_gpus": ctx.world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": prec, "data": "synthetic",
             "config": {"workload": f"reversi8x8_net_forward_batch{B}_{prec}",
                        "positions": "fixture F1 positions tiled to the batch"},
             "roofline": {"bound": "mfma", "kernel": "f8::k_tower_fp8" if fp8 else "k_tower_bf16", "achieved": ach,
-                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": launches,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": tr, "traffic_source": tr_src, "launches": launches,
                          "avg_launch_ms": avg_ms, "flop_per_launch": B * NET_FLOP_PER_POS}}
 
 
@@ -440,13 +457,14 @@ def run_env(ctx, n, K, W):
     launches, timed, ms = _lib.profile_read()["env_step"]
     assert launches == timed == K and int((status == _lib.ST_ILLEGAL).sum()) == 0
     avg_ms = ms / timed
+    tr, tr_src = pmc_traffic("k_reversi_step", games=n)
     ach = 42.0 * n / (avg_ms * 1e-3) / 1e9
     return {"metric": "env_steps_per_s", "value": n * K * ctx.world / dt, "unit": "steps/s", "n_gpus": ctx.world, "steps": K,
             "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"reversi8x8_env_step_{n}games", "positions": "random stones, lowest legal move"},
             "roofline": {"bound": "hbm", "kernel": "k_reversi_step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches, "avg_launch_ms": avg_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": 42.0 * n,
                          "note": "bound by integer VALU issue, not HBM: 350 VALU instructions per step (8 x 15 carry-propagation "
                                  "flips + ~150 legal mask + ~60 I/O and status) at 4 cycles per wave64 instruction keep the "
@@ -487,6 +505,7 @@ def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
     avg_ms = ms / max(timed, 1)
     tb = tree_bytes(cnt)
     ach = tb / max(launches, 1) / (avg_ms * 1e-3) / 1e9
+    tr, tr_src = pmc_traffic("k_search_fused_ttt", games=B, sims=sims, ttt_lanes=ttt_lanes if ttt_lanes > 0 else 4) if ttt_lanes >= 0 else (None, None)
     return {"metric": "selfplay_games_per_s", "value": K * B * ctx.world / dt, "unit": "games/s", "n_gpus": ctx.world,
             "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "data": "synthetic", "dtype": "u64+f32",
@@ -495,7 +514,7 @@ def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
                        "ttt_lanes": ttt_lanes if ttt_lanes else 4},
             "roofline": {"bound": "hbm", "kernel": "k_search_fused_ttt<%s, uniform>" % (ttt_lanes if ttt_lanes > 0 else 4) if ttt_lanes >= 0
                          else "k_search_fused<TicTacToe> (generic)", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "launches": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tb / max(launches, 1)},
             "sims_per_s": cnt["n_sims"] * ctx.world / dt, "counters": cnt}
 
@@ -678,10 +697,12 @@ def run_reversi(ctx, args, B, sims, K, W):
                 break
         tb = tree_bytes(cnt) * (prof_steps / K if (args.mode == "steady" and prof_steps < K) else 1.0)  # the timed steps' share
         t_union, t_sum = _lib.profile_union_ms("select")
+        t_tr, t_src = pmc_traffic("k_tree_step", games_per_launch=Bs, sims=sims) if prec == "bf16" else (None, None)
         out["roofline_tree"] = {"bound": "hbm", "kernels": "k_tree_step (expand + backup + select, 16 lanes per game)",
                                 "achieved": tb / (t_sum * 1e-3) / 1e9 if t_sum else None, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": tb / (t_sum * 1e-3) / 1e9 / HBM_PEAK_GBS if t_sum else None,
                                 "algorithmic_bytes": tb, "kernel_ms": t_sum, "launches": prof["select"][0],
+                                "traffic": t_tr * prof["select"][0] if t_tr else None, "traffic_per_launch": t_tr, "traffic_source": t_src,
                                 "note": "latency-bound pointer chase, overlapped with the other pipeline's net launch"}
         out["kernel_ms_total"] = {k: round(v[2], 3) for k, v in prof.items() if v[0]}
     else:

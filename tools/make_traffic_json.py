@@ -15,6 +15,7 @@ src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
 
 
 def mean(name, counter, kernel):
+    # pass names carry their suffix at the end: pmc_ttt_fetch_gw4 <- mean("pmc_ttt_fetch_gw4", ...)
     path = os.path.join(src, f"{tag}_{name}_pmc.csv")
     if not os.path.exists(path):
         return None
@@ -27,22 +28,32 @@ def mean(name, counter, kernel):
 out = {"source": f"tools/profile_round.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); "
                  "values in KB per launch, mean over launches",
        "correction": "MI355X_MICROARCH.md HBM section: hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts "
-                     "128-B requests at 64 B)"}
-for key, name, ppl_file in (("k_tower_bf16", "pmc_bench", "pmc_bench_fetch.json"), ("k_tower_bf16@4096", "pmc_tower", None)):
-    f, w = mean(name + "_fetch", "FETCH_SIZE", "k_tower_bf16"), mean(name + "_write", "WRITE_SIZE", "k_tower_bf16")
+                     "128-B requests at 64 B: exact for wide coalesced streaming reads; for the tree step's dependent 16-byte-per-lane "
+                     "loads the request size is not known, so its entry carries both readings)"}
+BENCH_CMD = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (two pipelines of 2048 games)"
+# key, pass name, kernel-name substring, shape (what bench.py must be running for the figure to apply), command
+for key, name, kern, shape, cmd in (
+        ("k_tower_bf16", "pmc_bench", "k_tower_bf16", None, BENCH_CMD),
+        ("k_tower_bf16@4096", "pmc_tower", "k_tower_bf16", {"positions_per_launch": 4096}, "python3 tools/bench_net.py 4096 60"),
+        ("k_tree_step", "pmc_bench", "k_tree_step", {"games_per_launch": 2048, "sims": 800}, BENCH_CMD),
+        ("k_search_fused_ttt", "pmc_ttt", "k_search_fused_ttt", {"games": 65536, "sims": 50, "ttt_lanes": 4},
+         "python3 bench.py --workload ttt --ttt-lanes 4 --steps 2 --warmup 1 --no-cpu-baseline"),
+        ("k_tower_fp8@8192", "pmc_fp8", "k_tower_fp8", {"positions_per_launch": 8192}, "python3 tools/bench_net.py 8192 60 fp8"),
+        ("k_reversi_step", "pmc_env", "k_reversi_step", {"games": 1 << 26}, "python3 tools/bench_env.py")):
+    suffix = "_gw4" if name == "pmc_ttt" else ""
+    f, w = mean(f"{name}_fetch{suffix}", "FETCH_SIZE", kern), mean(f"{name}_write{suffix}", "WRITE_SIZE", kern)
     if not f or not w:
         continue
-    ent = {"fetch_kb": f[0], "write_kb": w[0], "hbm_bytes_per_launch": int((2 * f[0] + w[0]) * 1024), "launches": f[1]}
-    if ppl_file:
+    ent = {"fetch_kb": f[0], "write_kb": w[0], "hbm_bytes_per_launch": int((2 * f[0] + w[0]) * 1024),
+           "hbm_bytes_per_launch_uncorrected": int((f[0] + w[0]) * 1024), "launches": f[1], "command": cmd}
+    if shape:
+        ent.update(shape)
+    if key == "k_tower_bf16":
         try:  # positions per launch of the very run the counters come from
-            d = json.load(open(os.path.join(src, f"{tag}_{ppl_file}")))
+            d = json.load(open(os.path.join(src, f"{tag}_pmc_bench_fetch.json")))
             ent["positions_per_launch"] = d["roofline"]["positions_per_launch"]
-            ent["command"] = "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (two pipelines of 2048 games)"
         except Exception:
             pass
-    else:
-        ent["positions_per_launch"] = 4096
-        ent["command"] = "python3 tools/bench_net.py 4096 60"
     out[key] = ent
 path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
 json.dump(out, open(path, "w"), indent=1)

@@ -33,7 +33,7 @@ if has pmc_bench; then
   run 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_bench_write" -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_bench_write.json" 2> "$OUT/pmc_bench_write.err"
 fi
 if has pmc_ttt; then
-  for gw in 2 0; do   # 2 = the TTT-specialised fused search, 0 = the generic fused kernel (the "before": --ttt-lanes -1)
+  for gw in 4 0; do   # 4 = the TTT-specialised fused search at its default lanes (cfg 2 as bench.py runs it), 0 = the generic fused kernel (--ttt-lanes -1)
     if [ $gw = 0 ]; then LANES="--ttt-lanes -1"; else LANES="--ttt-lanes $gw"; fi
     run 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS -d "$OUT/pmc_ttt_sq_gw$gw" -o t -- python3 bench.py --workload ttt $LANES --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_sq_gw$gw.json" 2> "$OUT/pmc_ttt_sq_gw$gw.err"
     run 200 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d "$OUT/pmc_ttt_tcc_gw$gw" -o t -- python3 bench.py --workload ttt $LANES --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_ttt_tcc_gw$gw.json" 2> "$OUT/pmc_ttt_tcc_gw$gw.err"
@@ -61,6 +61,8 @@ if has pmc_tree; then
 fi
 if has pmc_fp8; then
   run 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA -d "$OUT/pmc_fp8_sq" -o t -- python3 tools/bench_net.py 8192 60 fp8 > "$OUT/pmc_fp8_sq.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fp8_fetch" -o t -- python3 tools/bench_net.py 8192 60 fp8 > "$OUT/pmc_fp8_fetch.txt" 2>&1
+  run 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_fp8_write" -o t -- python3 tools/bench_net.py 8192 60 fp8 > "$OUT/pmc_fp8_write.txt" 2>&1
 fi
 if has clock; then
   # in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz) and per-phase stamps of the fused net kernel
@@ -68,8 +70,6 @@ if has clock; then
   FP8=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_fp8.txt" 2>&1
   TAPS=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_taps_bf16.txt" 2>&1   # cycles per conv tap (stamped variant)
   ZERO=1 run 300 bash tools/exp_stamps.sh > "$OUT/tower_clock_bf16_zero_weights.txt" 2>&1   # same instruction stream, operands that toggle nothing
-  run 300 bash tools/exp_ab_rowt.sh > "$OUT/ab_tower_rowt.txt" 2>&1            # row-tile units vs position-major, interleaved
-  run 300 bash tools/exp_ab_barrier.sh > "$OUT/ab_tower_barrier.txt" 2>&1      # ceiling of relaxing the per-layer barrier
 fi
 if has ab; then
   # cost of the in-library kernel timers on `value`, and 1 / 2 / 3 pipelines, interleaved on ONE device
@@ -79,6 +79,12 @@ if has ab; then
       run 200 python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-secondary $v > "$OUT/ab_${tagv}_$i.json" 2> /dev/null
     done
   done
+fi
+if has train; then
+  # the training step: per-kernel table of 200 replays of the captured step (tower on the HIP kernels), and the microbench
+  run 300 rocprofv3 --kernel-trace --stats -d "$OUT/train_step" -o t -- python3 tools/prof_train_step.py > "$OUT/train_step.txt" 2>&1
+  run 300 python3 tools/bench_train.py 64 4 1024 > "$OUT/bench_train.txt" 2>&1
+  run 300 python3 tools/bench_train.py 128 6 1024 --quick > "$OUT/bench_train_128ch_6blocks.txt" 2>&1
 fi
 # the result databases are tens of MB: summarise here, ship only the summaries
 python3 tools/summarize_prof.py "$TAG" --out "$OUT/summary" >&2
