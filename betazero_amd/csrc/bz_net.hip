@@ -493,14 +493,31 @@ __device__ __forceinline__ void load_b(v8i (&b)[4], const char* in, int boff, in
         if (u >= unit_lo(dy) && u < unit_hi(dy)) b[j] = ld32(in, boff ^ (ks << 6), (u + dy) * kRowC * kCell);
     }
 }
+#if defined(BZ_EXP_MFMA16_FP8) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_MFMA16_FP8 is a diagnostic variant: build it through betazero_amd.build.build_variant()"
+#endif
 template <int TAP>
-__device__ __forceinline__ void mfma4(f32x16 (&acc)[8], const v8i& a, const v8i (&b)[4], int pp) {
+__device__ __forceinline__ void mfma4(f32x16 (&acc)[8], const v8i& a, const v8i (&b)[4], int pp, [[maybe_unused]] int kpar = 0) {
     constexpr int dy = TAP / 3 - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int u = 4 * pp + j;
-        if (u >= unit_lo(dy) && u < unit_hi(dy))
+        if (u >= unit_lo(dy) && u < unit_hi(dy)) {
+#ifdef BZ_EXP_MFMA16_FP8
+            // TIMING ONLY (wrong results): the 32x32x64 MFMA as two v_mfma_scale_f32_16x16x128_f8f6f4 on the same operand
+            // registers (same MACs, 2 x 32 cycles) -- tools/exp_ab_mfma16.sh FP8=1; second product with swapped operands
+            // so that the compiler cannot merge the two
+            f32x16& c = acc[u];
+            f32x4 q0 = kpar ? f32x4{c[8], c[9], c[10], c[11]} : f32x4{c[0], c[1], c[2], c[3]};
+            f32x4 q1 = kpar ? f32x4{c[12], c[13], c[14], c[15]} : f32x4{c[4], c[5], c[6], c[7]};
+            q0 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b[j], q0, 0, 0, 0, kUnit, 0, kUnit);
+            q1 = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b[j], a, q1, 0, 0, 0, kUnit, 0, kUnit);
+            if (kpar) { c[8] = q0[0]; c[9] = q0[1]; c[10] = q0[2]; c[11] = q0[3]; c[12] = q1[0]; c[13] = q1[1]; c[14] = q1[2]; c[15] = q1[3]; }
+            else { c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3]; c[4] = q1[0]; c[5] = q1[1]; c[6] = q1[2]; c[7] = q1[3]; }
+#else
             acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b[j], acc[u], 0, 0, 0, kUnit, 0, kUnit);
+#endif
+        }
     }
 }
 
@@ -522,18 +539,22 @@ __device__ __forceinline__ void tap_step(f32x16 (&acc)[8], v8i (&A0)[2], v8i (&A
     int boff_n = boff;
     if constexpr (TAP_N % 3 != TAP % 3) boff_n = tap_off<TAP_N % 3 - 1>(r, h);
     load_b<TAP>(b1, in, boff, 0, 1);
-    mfma4<TAP>(acc, use[0], b0, 0);
+    mfma4<TAP>(acc, use[0], b0, 0, 0);
     load_b<TAP>(b0, in, boff, 1, 0);
-    mfma4<TAP>(acc, use[0], b1, 1);
+    mfma4<TAP>(acc, use[0], b1, 1, 0);
     load_b<TAP>(b1, in, boff, 1, 1);
-    mfma4<TAP>(acc, use[1], b0, 0);
+    mfma4<TAP>(acc, use[1], b0, 0, 1);
     if constexpr (!last) load_b<TAP_N>(b0, in, boff_n, 0, 0);  // first half-step of the next tap
-    mfma4<TAP>(acc, use[1], b1, 1);
+    mfma4<TAP>(acc, use[1], b1, 1, 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#ifdef BZ_EXP_MFMA16_FP8
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // the unit's 2 half-size MFMAs
+#else
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+#endif
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads
         }
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
