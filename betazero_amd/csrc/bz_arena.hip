@@ -23,13 +23,15 @@ using namespace bz;
 namespace {
 
 constexpr int kInf = 1000;       // stands for float("inf"): stone differences lie in [-64, 64]
-constexpr int kMaxDepth = 8;
+constexpr int kMaxDepth = 8;        // the batched kernel's per-lane stack (the arena's opponent)
+constexpr int kMaxDepthHost = 60;   // the scalar entry point: a game has at most 60 plies, so any depth the reference accepts
 
 // `self` = stones of the minimax player, `other` = the opponent's.  Returns the root's best score;
-// *best_move = bit index of the chosen move or -1 (None).
+// *best_move = bit index of the chosen move or -1 (None).  MAXD = the deepest max_depth this instance can hold.
+template <int MAXD>
 BZ_HD int rev_minimax(u64 self, u64 other, int max_depth, u64 valid, int* best_move) {
-    u64 st_self[kMaxDepth + 1], st_other[kMaxDepth + 1], st_moves[kMaxDepth + 1];
-    int st_best[kMaxDepth + 1], st_bm[kMaxDepth + 1], st_cur[kMaxDepth + 1];
+    u64 st_self[MAXD + 1], st_other[MAXD + 1], st_moves[MAXD + 1];
+    int st_best[MAXD + 1], st_bm[MAXD + 1], st_cur[MAXD + 1];
     *best_move = -1;
     u64 ls = rev_legal(self, other, valid), lo = rev_legal(other, self, valid);
     if (max_depth <= 0 || (ls == 0 && lo == 0)) return popc64(self) - popc64(other);
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(64) k_reversi_minimax(const u64* __restrict__ 
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     int bm = -1, sc = 0;
-    if (!active || active[i]) sc = rev_minimax(self[i], other[i], depth, valid, &bm);
+    if (!active || active[i]) sc = rev_minimax<kMaxDepth>(self[i], other[i], depth, valid, &bm);
     move[i] = (int8_t)bm;
     score[i] = (int16_t)sc;
 }
@@ -156,10 +158,10 @@ bool size_ok(int32_t s) { return s == 4 || s == 6 || s == 8; }
 
 BZ_EXPORT int32_t bz_reversi_minimax(uint64_t self, uint64_t other, int32_t size, int32_t max_depth, int32_t* move,
                                      int32_t* score) {
-    BZ_REQUIRE(size_ok(size) && max_depth >= 0 && max_depth <= kMaxDepth && move && score,
-               "bz_reversi_minimax: size must be 4, 6 or 8 and 0 <= max_depth <= 8");
+    BZ_REQUIRE(size_ok(size) && max_depth >= 0 && move && score, "bz_reversi_minimax: size must be 4, 6 or 8 and max_depth >= 0");
+    if (max_depth > kMaxDepthHost) max_depth = kMaxDepthHost;  // no line of play is longer: deeper limits search the same tree
     int bm;
-    *score = rev_minimax(self, other, max_depth, rev_valid(size), &bm);
+    *score = rev_minimax<kMaxDepthHost>(self, other, max_depth, rev_valid(size), &bm);
     *move = bm;
     return BZ_OK;
 }

@@ -60,15 +60,12 @@ class OptimalPlayer(Player):
 class ReversiOptimalPlayer(ReversiPlayer):
     """The reference's Reversi OptimalPlayer (src/reversi/players/reversi_players.py:35-77): depth-limited
     minimax on the stone difference, no pass rule inside the search, random.choice when no move scores above
-    -inf -- on bz_reversi_minimax (0 <= max_depth <= 8)."""
-
-    MAX_DEPTH = 8  # the minimax kernel's explicit stack (bz_reversi_minimax); the reference's recursion has no limit
+    -inf -- on bz_reversi_minimax.  Any max_depth >= 0, like the reference's recursion (the scalar entry point keeps a
+    stack of 60 frames -- no line of play is longer; only the BATCHED kernel of the arena is limited to depth 8)."""
 
     def __init__(self, symbol, max_depth=4):
-        if not 0 <= int(max_depth) <= self.MAX_DEPTH:
-            raise ValueError(f"ReversiOptimalPlayer: max_depth must be in 0..{self.MAX_DEPTH} (got {max_depth}); the "
-                             "library's minimax keeps an explicit stack of that depth -- a known difference from the "
-                             "reference's unbounded recursion (INTEGRATION.md)")
+        if int(max_depth) < 0:
+            raise ValueError(f"ReversiOptimalPlayer: max_depth must be >= 0 (got {max_depth})")
         self.symbol, self.max_depth = symbol, int(max_depth)
 
     def minimax(self, board, is_maximizing=True, depth=0):

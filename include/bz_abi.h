@@ -128,7 +128,8 @@ int32_t bz_augment_d4_batch(const uint64_t* own, const uint64_t* opp, const floa
 /* row 3), one game per lane, and as scalar host entry points.               */
 /* ------------------------------------------------------------------------ */
 /* OptimalPlayer.minimax  src/reversi/players/reversi_players.py:41-69 with evaluate_board :71-77:
- * depth-limited (0 <= max_depth <= 8), stone difference for the player, moves in
+ * depth-limited (any max_depth >= 0 for the scalar entry point; 0 <= max_depth <= 8 for the batched kernel, whose
+ * stack lives in a lane's registers / scratch), stone difference for the player, moves in
  * generate_possible_moves order, first strictly better score wins, no pass rule inside the
  * search (a side without a move in an unfinished game scores -inf / +inf: the reference's
  * behaviour).  self = the player's stones, other = the opponent's; the player is to move.

@@ -168,15 +168,27 @@ def test_reversi_minimax_random_positions_vs_game_api_restatement():
     assert n_none > 10
 
 
-def test_reversi_optimal_player_refuses_depths_the_kernel_cannot_hold():
-    """the library's minimax keeps an explicit stack of depth 8 (the reference recurses without a limit): a clear
-    ValueError at construction / at the arena call instead of a generic error at play time"""
+def test_reversi_optimal_player_takes_any_depth_like_the_reference_and_the_batched_kernel_says_its_limit():
+    """the reference's OptimalPlayer recurses to whatever max_depth it is given (reversi_players.py:36-38).  The scalar
+    entry point keeps 60 stack frames -- no line of play is longer -- so the player accepts every depth: depth 12 on a
+    4x4 board (a game there has at most 12 plies) is the full-depth search and equals the Game-API minimax move for move;
+    depth 1000 searches the same tree.  Only the BATCHED kernel (the arena's opponent) holds 8 levels and says so."""
     import pytest
     with pytest.raises(ValueError, match="max_depth"):
-        bz.ReversiOptimalPlayer(1, max_depth=9)
-    with pytest.raises(ValueError, match="max_depth"):
         bz.ReversiOptimalPlayer(1, max_depth=-1)
-    assert bz.ReversiOptimalPlayer(1, max_depth=8).max_depth == 8
+    b = bz.ReversiBoard(size=4)
+    player, moves = 1, 0
+    while not b.is_game_over() and moves < 4:
+        if b.generate_possible_moves(player):
+            sc12, mv12 = bz.ReversiOptimalPlayer(player, max_depth=12).minimax(b)
+            sc_big, mv_big = bz.ReversiOptimalPlayer(player, max_depth=1000).minimax(b)
+            ref_sc, ref_mv = _py_minimax(b, player, 12)
+            assert (sc12, mv12) == (ref_sc, ref_mv) == (sc_big, mv_big), (moves, sc12, mv12, ref_sc, ref_mv)
+            # (None = the reference's quirk: every line ends in a forced pass, which its search scores -inf -> random.choice)
+            b = b.make_move(*(mv12 or b.generate_possible_moves(player)[0]), player)
+            moves += 1
+        player = -player
+    assert bz.ReversiOptimalPlayer(1, max_depth=9).max_depth == 9
     from betazero_amd.arena import play_arena
     with pytest.raises(ValueError, match="opponent_depth"):
         play_arena("reversi", 4, 8, opponent_depth=9)
