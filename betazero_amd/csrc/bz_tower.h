@@ -93,9 +93,20 @@ template <int C_, int P_ = 512 / C_, bool M16_ = false> struct Tw {
     static __device__ __forceinline__ int sw(int sel, int xx) {
         return C == 64 ? (((xx & 7) >> 1) | ((sel & 1) << 2)) : ((xx & 7) | ((sel & 1) << 3));
     }
+    // M16 (the 16x16x32 path) places chunk ch of a cell in column xx at 16-byte position sigma((ch + 2 xx) mod 16),
+    // sigma(s) = s >> 1 | (s & 1) << 3 -- additive in the column, so that a tap's column shift moves every lane's slot by
+    // the same amount: in a ds_read_b128 lane group the two positions of a column differ in the parity of the reader's
+    // k-group (slots 2h, 2h + 1) and the eight columns in h, for EVERY tap (the XOR swizzle above pairs lanes across
+    // k-groups differently for shifted taps: 41 % conflict cycles when the 16x16x32 path first ran on it); sigma keeps
+    // the 8-byte epilogue stores of a 16-lane group on 8 distinct 16-byte positions mod 128 B (2-way, as before).
+    static __device__ __forceinline__ int pos16(int ch, int xx) {
+        const int s = (ch + 2 * (xx & 7)) & 15;
+        return ((s >> 1) | ((s & 1) << 3)) << 4;
+    }
     // byte offset of 16-byte chunk k of board cell c of the workgroup's position p, inside that position
     static __device__ __forceinline__ int cell_off(int p, int c, int k) {
-        return cell_at(c >> 3, c & 7) + ((k ^ sw(ROWT ? p : c >> 3, c & 7)) << 4);
+        if constexpr (M16) return cell_at(c >> 3, c & 7) + pos16(k, c & 7);
+        else return cell_at(c >> 3, c & 7) + ((k ^ sw(ROWT ? p : c >> 3, c & 7)) << 4);
     }
     // unit u, lane column r (0..31) -> position inside the wave and board cell
     static __device__ __forceinline__ int unit_pos(int u, int r) { return ROWT ? r >> 3 : u >> 1; }
@@ -403,23 +414,27 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[G::MW][G::NU], char* out,
 // and from L2 are those of the 32x32x16 path, and so are the cycles (an MFMA of this shape is 16 cycles for half the
 // MACs).  What changes is the clock the chip holds: MI355X_MICROARCH.md (DVFS give-back, item 7) reports 1.12-1.15 x the
 // FLOP/s for this shape at equal cycles; measured on this kernel 1.86 -> 2.00 GHz (profiles/r04_ab_tower_16x16.txt).
-// The LDS image and its swizzle are unchanged: with chunk = 4 kq + g the 16 lanes of every ds_read_b128 lane group
-// ({0-3, 12-15, 20-27}, ...) still hit 16 distinct 16-byte slots for every tap (g differs by 1 exactly where the
-// (position, column) sets of the group's two halves are disjoint under XOR 1).
+// The LDS image keeps its cells (9 per row, halo included) but places a cell's chunks by Tw::pos16 instead of the XOR
+// swizzle: the 16 lanes of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) are the 16 (position, column) cells of a
+// half-unit, the two positions of a column read by k-groups of opposite parity -- pos16 keeps them on 16 distinct slots
+// for every tap.
 template <class G> struct WSets16 { bf16x8 s[2][G::KQ][2]; };  // two register sets x KQ steps x 2 channel halves
 
+// the lane's B offsets for the KQ steps of tap TAP (half b = 0, board row 0): chunk 4 kq + g of the cell in column x + dx
 template <class G, int TAP>
-__device__ __forceinline__ int tap_off16(int c, int g) {  // lane's B offset for sub-step (kq = 0, b = 0) of tap TAP, row 0
+__device__ __forceinline__ void tap_off16(int c, int g, int (&boff)[G::KQ]) {
     constexpr int dx = TAP % 3 - 1;
     const int xx = (c & 7) + dx;
-    return (c >> 3) * G::TILE + G::cell_at(0, xx) + ((G::sw(c >> 3, xx) ^ g) << 4);
+    const int cell = (c >> 3) * G::TILE + G::cell_at(0, xx);
+#pragma unroll
+    for (int kq = 0; kq < G::KQ; ++kq) boff[kq] = cell + G::pos16(4 * kq + g, xx);
 }
 template <class G, int TAP>
-__device__ __forceinline__ void load_b16(bf16x8 (&b)[G::NU], const char* in, int boff, int kq, int half) {
+__device__ __forceinline__ void load_b16(bf16x8 (&b)[G::NU], const char* in, int boff, int half) {
     constexpr int dy = TAP / 3 - 1;
 #pragma unroll
     for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u)
-        b[u] = *reinterpret_cast<const bf16x8*>(in + (boff ^ (kq << 6)) + half * 2 * G::TILE + G::unit_imm(u) + dy * G::ROWC * G::CELL);
+        b[u] = *reinterpret_cast<const bf16x8*>(in + boff + half * 2 * G::TILE + G::unit_imm(u) + dy * G::ROWC * G::CELL);
 }
 template <int Q>
 __device__ __forceinline__ void mfma16_quarter(f32x16& c, const bf16x8& a, const bf16x8& b) {
@@ -438,8 +453,8 @@ __device__ __forceinline__ void mfma_units16(f32x16 (&acc)[G::MW][G::NU], const 
 }
 // one conv tap: 2 KQ sub-steps; the register set freed by the previous tap is filled for the next one
 template <int S, int TAP, class G>
-__device__ __forceinline__ void tap_step16(f32x16 (&acc)[G::MW][G::NU], WSets16<G>& WS, const uint4*& ap, const char* in, int& boff,
-                                           int lane, bf16x8 (&B)[2][G::NU]) {
+__device__ __forceinline__ void tap_step16(f32x16 (&acc)[G::MW][G::NU], WSets16<G>& WS, const uint4*& ap, const char* in,
+                                           int (&boff)[G::KQ], int lane, bf16x8 (&B)[2][G::NU]) {
     constexpr bool last = TAP == 8;
     constexpr int TAP_N = last ? TAP : TAP + 1;
     bf16x8 (&use)[G::KQ][2] = WS.s[S];
@@ -449,13 +464,15 @@ __device__ __forceinline__ void tap_step16(f32x16 (&acc)[G::MW][G::NU], WSets16<
 #pragma unroll
         for (int a = 0; a < 2; ++a) nxt[kq][a] = __builtin_bit_cast(bf16x8, BZ_WLOAD(&ap[(kq * G::MT * 2 + a) * 64 + (unsigned)lane]));
     ap += G::KQ * G::MT * 2 * 64;
-    int boff_n = boff;
-    if constexpr (TAP_N % 3 != TAP % 3) boff_n = tap_off16<G, TAP_N>(lane & 15, lane >> 4);
+    int boff_n[G::KQ];
+#pragma unroll
+    for (int kq = 0; kq < G::KQ; ++kq) boff_n[kq] = boff[kq];
+    if constexpr (TAP_N % 3 != TAP % 3) tap_off16<G, TAP_N>(lane & 15, lane >> 4, boff_n);
     constexpr int NS = 2 * G::KQ;  // sub-steps; sub-step ss sits in buffer ss & 1 (NS is even: every tap starts in buffer 0)
 #pragma unroll
     for (int ss = 0; ss < NS; ++ss) {
-        if (ss + 1 < NS) load_b16<G, TAP>(B[(ss + 1) & 1], in, boff, (ss + 1) >> 1, (ss + 1) & 1);
-        else if constexpr (!last) load_b16<G, TAP_N>(B[0], in, boff_n, 0, 0);  // first sub-step of the next tap
+        if (ss + 1 < NS) load_b16<G, TAP>(B[(ss + 1) & 1], in, boff[(ss + 1) >> 1], (ss + 1) & 1);
+        else if constexpr (!last) load_b16<G, TAP_N>(B[0], in, boff_n[0], 0);  // first sub-step of the next tap
         if (ss & 1) mfma_units16<G, TAP, 1>(acc, use[ss >> 1], B[1]);
         else mfma_units16<G, TAP, 0>(acc, use[ss >> 1], B[0]);
     }
@@ -469,12 +486,13 @@ __device__ __forceinline__ void tap_step16(f32x16 (&acc)[G::MW][G::NU], WSets16<
         }
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read (weight prefetch)
     }
-    boff = boff_n;
+#pragma unroll
+    for (int kq = 0; kq < G::KQ; ++kq) boff[kq] = boff_n[kq];
     __builtin_amdgcn_sched_barrier(0);  // one tap per scheduling region
 }
 template <int S0, int TAP, class G>
-__device__ __forceinline__ void run_taps16(f32x16 (&acc)[G::MW][G::NU], WSets16<G>& WS, const uint4*& ap, const char* in, int& boff,
-                                           int lane, bf16x8 (&B)[2][G::NU]) {
+__device__ __forceinline__ void run_taps16(f32x16 (&acc)[G::MW][G::NU], WSets16<G>& WS, const uint4*& ap, const char* in,
+                                           int (&boff)[G::KQ], int lane, bf16x8 (&B)[2][G::NU]) {
     if constexpr (TAP < 9) {
         tap_step16<(S0 + TAP) & 1, TAP, G>(acc, WS, ap, in, boff, lane, B);
         run_taps16<S0, TAP + 1, G>(acc, WS, ap, in, boff, lane, B);
@@ -492,14 +510,13 @@ template <class G>
 __device__ __forceinline__ void epilogue16(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt,
                                            int lane) {
     const int c = lane & 15, g = lane >> 4, x = c & 7, pl = c >> 3;
-    const int swz = G::sw(pl, x);
     // per-lane bases of unit 0 / unit 1 (even / odd rows) of the lane's position in half b = 0; + 8 (g & 1): the lane's 4
     // channels are the lower or upper half of a 16-byte chunk
     int home2[2] = {pl * G::TILE + G::cell_at(0, x) + 8 * (g & 1), pl * G::TILE + G::cell_at(1, x) + 8 * (g & 1)};
     asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        const int slot = ((4 * wt + 2 * a + (g >> 1)) ^ swz) << 4;
+        const int slot = G::pos16(4 * wt + 2 * a + (g >> 1), x);
         const f32x4 bq = bias.q[0][a];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -560,11 +577,11 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, bool secon
         static_assert(G::ROWT && G::MW == 1 && G::C == 128, "the 16x16x32 path serves the row-tile shape of the 128-channel net");
         bf16x8 B[2][G::NU];
         const int lane = 32 * h + r;
-        boff[0] = tap_off16<G, 0>(lane & 15, lane >> 4);
-        boff[1] = 0;
-        load_b16<G, 0>(B[0], in, boff[0], 0, 0);
+        int boff16[G::KQ];
+        tap_off16<G, 0>(lane & 15, lane >> 4, boff16);
+        load_b16<G, 0>(B[0], in, boff16[0], 0);
         __builtin_amdgcn_sched_barrier(0);
-        run_taps16<S0, 0, G>(acc, WS, ap, in, boff[0], lane, B);
+        run_taps16<S0, 0, G>(acc, WS, ap, in, boff16, lane, B);
     } else if constexpr (G::ROWT) {
         bf16x8 B[G::NBUF][G::NU];
         tap_off<G, 0>(r, h, boff);
