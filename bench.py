@@ -695,6 +695,8 @@ def run_reversi(ctx, args, B, sims, K, W):
                 out["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({path}: "
                                                      f"{tp:.0f} positions per launch; this run: {ppl:.0f})")
                 break
+        if out["roofline"]["traffic"] is None:
+            out["roofline"]["traffic_note"] = "no --pmc FETCH_SIZE / WRITE_SIZE pass has been committed for this shape (precision, pipelines, positions per launch)"
         tb = tree_bytes(cnt) * (prof_steps / K if (args.mode == "steady" and prof_steps < K) else 1.0)  # the timed steps' share
         t_union, t_sum = _lib.profile_union_ms("select")
         t_tr, t_src = pmc_traffic("k_tree_step", games_per_launch=Bs, sims=sims) if prec == "bf16" else (None, None)
