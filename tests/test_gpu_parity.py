@@ -1147,17 +1147,19 @@ def test_net_bf16_every_conv_stage_on_its_own_vs_oracle():
     print("per-stage bf16 net: worst |dlogit| %.2e  |dv| %.2e" % worst)
 
 
-def test_net_bf16_every_conv_stage_on_its_own_throughput_shape_vs_oracle():
+@pytest.mark.parametrize("n,stride", [(301, 8), (1848, 41)], ids=["301_positions", "bench_launch_1848_positions"])
+def test_net_bf16_every_conv_stage_on_its_own_throughput_shape_vs_oracle(n, stride):
     """the same 13 stage-isolating nets through the THROUGHPUT shape of the fused kernel (batches > 256 positions:
-    Tw<128, 4>, four positions per workgroup, row-tile units that skip the padding-row MFMAs -- the headline kernel):
-    301 positions (a ragged last workgroup), every 8th row and the last rows compared with the oracle per stage, so
-    the row-tile skip logic is pinned layer by layer and not only through the whole net."""
+    Tw<128, 4, true>, four positions per workgroup, row-tile units that skip the padding-row MFMAs, the K-loop on
+    v_mfma_f32_16x16x32_bf16 since round 4 -- the headline kernel): 301 positions (a ragged last workgroup) and 1848 (what
+    one launch of bench.py's two pipelines evaluates: 462 workgroups, nearly two rounds of the chip), a strided sample of
+    rows and the last rows compared with the oracle per stage, so the row-tile skip logic and the new lane map are pinned
+    layer by layer and not only through the whole net."""
     from betazero_amd.net import DeviceNet
     m = _net(128, 6, bf16=True)
-    n = 301
     own, opp = _positions(n, seed=13)
-    pick = np.unique(np.concatenate([np.arange(0, n, 8), np.arange(n - 5, n)]))
-    dn = DeviceNet.from_module(m, 512)
+    pick = np.unique(np.concatenate([np.arange(0, n, stride), np.arange(n - 5, n)]))
+    dn = DeviceNet.from_module(m, 2048)
     worst = (0.0, 0.0)
     for stage in range(13):
         mm = _stage_isolating_params(m, stage)
