@@ -8,7 +8,8 @@ so that stem, heads, losses and the optimiser stay plain torch (the loop shape o
 
 bf16 activations and gradients, fp32 accumulation, fp32 master weights (the kernels repack W into their bf16 fragment
 streams every step -- 2 x 147 k values per layer at C = 128).  There is no CPU path: without the HIP library or a GPU
-this raises; PolicyValueNet falls back to nothing by itself -- it uses these kernels only when asked to (fused_tower)."""
+this raises.  PolicyValueNet uses these kernels when its forward() is handed a TowerPlan (fused_tower form); its plain
+forward() is the torch definition of the same net (CPU tests, the fp32 reference of the GPU tests)."""
 import torch
 
 from . import _lib
@@ -127,18 +128,3 @@ def tower_apply(x0, W, b, plan):
 def tower_apply_nhwc(x0, W, b, plan):
     """the same on [n, 64 cells, C] tensors -- the kernels' own layout (what PolicyValueNet's fused path passes)"""
     return _TowerFn.apply(x0, W, b, plan, True)
-
-
-def tower_reference(x0, W, b, round_bf16=True, relu_masks=None):
-    """the same residual tower in plain torch (conv2d + relu + skip) -- the autograd reference of the GPU tests.
-    round_bf16: round every layer's output to bf16 (straight-through), as the kernels store it.  relu_masks: a list
-    of L boolean [n, C, 8, 8] tensors; layer l's ReLU then is "multiply by relu_masks[l]" -- with the kernels' own
-    patterns (act[l + 1] > 0) the reference takes the same branch of every ReLU as the kernels did."""
-    import torch.nn.functional as F
-    rnd = (lambda t: t + (t.bfloat16().float() - t).detach()) if round_bf16 else (lambda t: t)
-    act = (lambda z, l: F.relu(z)) if relu_masks is None else (lambda z, l: z * relu_masks[l])
-    a = x0
-    for blk in range(W.shape[0] // 2):
-        h = rnd(act(F.conv2d(a, W[2 * blk], b[2 * blk], padding=1), 2 * blk))
-        a = rnd(act(F.conv2d(h, W[2 * blk + 1], b[2 * blk + 1], padding=1) + a, 2 * blk + 1))
-    return a

@@ -20,6 +20,21 @@ def _case(C, L, n, seed):
     return [t.to(DEV) for t in (x0, W, b, gy)]
 
 
+def tower_reference(x0, W, b, round_bf16=True, relu_masks=None):
+    """the same residual tower in plain torch (conv2d + relu + skip) -- the autograd reference of the GPU tests.
+    round_bf16: round every layer's output to bf16 (straight-through), as the kernels store it.  relu_masks: a list
+    of L boolean [n, C, 8, 8] tensors; layer l's ReLU then is "multiply by relu_masks[l]" -- with the kernels' own
+    patterns (act[l + 1] > 0) the reference takes the same branch of every ReLU as the kernels did."""
+    import torch.nn.functional as F
+    rnd = (lambda t: t + (t.bfloat16().float() - t).detach()) if round_bf16 else (lambda t: t)
+    act = (lambda z, l: F.relu(z)) if relu_masks is None else (lambda z, l: z * relu_masks[l])
+    a = x0
+    for blk in range(W.shape[0] // 2):
+        h = rnd(act(F.conv2d(a, W[2 * blk], b[2 * blk], padding=1), 2 * blk))
+        a = rnd(act(F.conv2d(h, W[2 * blk + 1], b[2 * blk + 1], padding=1) + a, 2 * blk + 1))
+    return a
+
+
 def _rel(a, b):
     a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
@@ -59,7 +74,7 @@ def test_tower_gradients_vs_torch_autograd_fp32(C, L, n):
     activations AND gradients in bf16 between layers, the reference keeps gradients in fp32: agreement to ~1 % of
     each tensor's range is what bf16 storage allows (measured on MI355X: mean error 2e-3 .. 3e-3 of the mean magnitude,
     dW / db within 1.2 % of their range)."""
-    from betazero_amd.train_kernels import TowerPlan, tower_apply, tower_reference
+    from betazero_amd.train_kernels import TowerPlan, tower_apply
     x0, W, b, gy = _case(C, L, n, 2)
     plan = TowerPlan(C, L, n)
     xs, Ws, bs = (t.clone().requires_grad_(True) for t in (x0, W, b))
