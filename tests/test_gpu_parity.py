@@ -1713,6 +1713,35 @@ def test_pipeline_streams_probe_rejects_a_serialising_pair_in_a_fresh_process():
     assert all(c >= 1.5 for c in cand[:out["info"]["picked"]])  # everything before the pick was rejected for a reason
 
 
+def test_cfg3_full_size_two_pipelines_equal_one_engine_bit_for_bit():
+    """the headline's exact configuration -- PipelinedSelfPlay: 2 x 2048 games on two streams, 800 simulations, bf16 MFMA
+    net, openings + tau = 1 -- for two moves against ONE engine holding all 4096 games on the default stream: the same
+    example rows bit for bit (positions, actions, pi bits, movers), the same work counters, no error flag.  Rows do not
+    depend on their batch neighbours, on the stream, or on the host thread's bounded run-ahead."""
+    from betazero_amd.engine import PipelinedSelfPlay
+    from betazero_amd.net import DeviceNet
+    B, sims = 4096, 800
+    dn = DeviceNet.from_module(_net(128, 6, bf16=True), B)
+    kw = dict(temp_moves=8, openings=1, seed=0, rounds=1)
+    sp = PipelinedSelfPlay("reversi", B, sims, "net_bf16", dn, pipelines=2, **kw)
+    one = _engine("reversi", B, sims, "net_bf16", net=dn, **kw)
+    sp.reset_games(); sp.reset_counters()
+    one.reset_games(); one.reset_counters()
+    for _ in range(2):
+        sp.step(False)
+        one.search(); one.play(False)
+    assert sp.status() == (B, 0) and one.status() == (B, 0)   # status() raises on any engine error flag
+    a = [e.example_tensors() for e in sp.engines]
+    b = one.example_tensors()
+    for f in ("own", "opp", "act", "mover"):
+        got = torch.cat([t[f][0, :, :2] for t in a]).cpu().numpy()
+        assert np.array_equal(got, b[f][0, :, :2].cpu().numpy()), f
+    got = torch.cat([t["pi"][0, :, :2] for t in a]).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), b["pi"][0, :, :2].cpu().numpy().view(np.uint32))
+    ca, cb = sp.counters(), one.counters()
+    assert ca == cb and ca["n_sims"] == 2 * B * sims and ca["n_net_leaves"] == ca["n_sims"] + 2 * B, (ca, cb)
+
+
 def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     """`python bench.py --gpus 2` for real -- two rank processes with real engines, the timed region, the ONE all-gather
     of the example blocks, max-over-ranks timing and the per-rank proof -- as far as one GPU allows: the ranks share the
