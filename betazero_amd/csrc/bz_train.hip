@@ -236,29 +236,37 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 // ---- backward-weights
 // LDS images for the transpose reads, both [cell][channel] with the 64-byte pieces of a cell XOR-swizzled by the cell
 // index so that the four cells of a ds_read_b64_tr_b16 block (4 consecutive cells x 64 B per 32-lane half) fall on
-// four different 64-byte bank windows: C = 128 (256-B cells): piece ^= idx & 3; C = 64 (128-B cells): piece ^= (idx >> 1) & 1.
-//   activations: 10 rows x 9 cells + 1 (rows -1 .. 8, columns -1 .. 8; idx = 9 (y + 1) + x + 1): the zero ring makes
-//                every tap shift a plain address offset
-//   gradients  : 64 cells, idx = 8 y + x
+// four different 64-byte bank windows: 256-B cells: piece ^= idx & 3; 128-B cells: piece ^= (idx >> 1) & 1.
+//   activations: 10 rows x 9 cells + 1 (rows -1 .. 8, columns -1 .. 8; idx = 9 (y + 1) + x + 1), all C channels: the zero
+//                ring makes every tap shift a plain address offset
+//   gradients  : 64 cells (idx = 8 y + x) x the workgroup's 64 output channels
+// A workgroup owns ALL NINE taps of one layer for 64 output channels (all of them at C = 64, one half at C = 128) and a
+// slice of the batch: every activation tile is read once (twice at C = 128), every gradient tile once.  (The first
+// version gave a workgroup one tap row and all channels: three workgroups re-read every tile -- 393 MB per step at C =
+// 64, which bound the kernel: 76 us where the matrix work is 15.)
 template <int C_> struct Wg {
     static constexpr int C = C_, MT = C / 32, CELL = 2 * C, ZC = CELL / 16;
-    static constexpr int NTW = MT * MT / 4;                 // N tiles (32 output channels) per wave
+    static constexpr int NH = C / 64;                       // workgroups that share a (layer, slice): one per 64 output channels
+    static constexpr int NTW = MT / 2;                      // N tiles (32 output channels) per wave: 1 (C = 64), 2 (C = 128)
+    static constexpr int GCELL = 128, GZC = 8;              // the workgroup's 64 output channels of a gradient cell
     static constexpr int P2 = 256 / C;                      // positions per stage
-    static constexpr int ACELLS = 91, A_TILE = ACELLS * CELL, G_TILE = 64 * CELL;
+    static constexpr int ACELLS = 91, A_TILE = ACELLS * CELL, G_TILE = 64 * GCELL;
     static constexpr int STAGE = P2 * (A_TILE + G_TILE);
-    static constexpr int NLD = P2 * 64 * ZC / 256;          // 16-byte loads per thread, tensor and stage
+    static constexpr int NLA = P2 * 64 * ZC / 256, NLG = P2 * 64 * GZC / 256;  // 16-byte loads per thread and stage
     static constexpr int LDS = 2 * STAGE;
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
-    static __device__ __forceinline__ int swz(int idx) { return C == 128 ? (idx & 3) : ((idx >> 1) & 1); }
-    static __device__ __forceinline__ int a_off(int p, int idx, int piece) { return p * A_TILE + idx * CELL + ((piece ^ swz(idx)) << 6); }
-    static __device__ __forceinline__ int g_off(int p, int idx, int piece) { return P2 * A_TILE + p * G_TILE + idx * CELL + ((piece ^ swz(idx)) << 6); }
+    static __device__ __forceinline__ int a_swz(int idx) { return C == 128 ? (idx & 3) : ((idx >> 1) & 1); }
+    static __device__ __forceinline__ int a_off(int p, int idx, int piece) { return p * A_TILE + idx * CELL + ((piece ^ a_swz(idx)) << 6); }
+    static __device__ __forceinline__ int g_off(int p, int idx, int piece) {
+        return P2 * A_TILE + p * G_TILE + idx * GCELL + ((piece ^ ((idx >> 1) & 1)) << 6);
+    }
 };
 
 struct WgradArgs {
     const __bf16* acts;   // act[0 .. L-1]   [L][n][64][C]
     const __bf16* gs;     // g[1 .. L]       [L][n][64][C]
-    float* partial;       // [L][3 dy][S][3 dx][ci][co]
-    float* db_partial;    // [L][S][co]: sum of g over the slice's (position, cell) -- the bias gradient's partial sums
+    float* partial;       // [L][S][9 taps][ci][co]
+    float* db_partial;    // [L][2 S][co]: sums of g over the slice's (position, cell), one per k half -- the bias gradient's partial sums
     int n, L, S;
 };
 
@@ -272,18 +280,27 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* lds, int a0, int a1) {
 
 // a stage's activations and gradients: HBM -> registers (issued a stage ahead) -> the LDS images
 template <class G>
-__device__ __forceinline__ void wg_fetch(u32x4 (&ra)[G::NLD], u32x4 (&rg)[G::NLD], const u32x4* A, const u32x4* Gr, int s, int tid) {
+__device__ __forceinline__ void wg_fetch(u32x4 (&ra)[G::NLA], u32x4 (&rg)[G::NLG], const u32x4* A, const u32x4* Gr, int s, int half, int tid) {
     const size_t base = (size_t)s * G::P2 * 64 * G::ZC;
 #pragma unroll
-    for (int j = 0; j < G::NLD; ++j) { ra[j] = A[base + tid + 256 * j]; rg[j] = Gr[base + tid + 256 * j]; }
+    for (int j = 0; j < G::NLA; ++j) ra[j] = A[base + tid + 256 * j];
+#pragma unroll
+    for (int j = 0; j < G::NLG; ++j) {  // chunk k (0..7) of the workgroup's half of cell (p, c)
+        const int i = tid + 256 * j, k = i % G::GZC, pc = i / G::GZC;
+        rg[j] = Gr[base + (size_t)pc * G::ZC + half * G::GZC + k];
+    }
 }
 template <class G>
-__device__ __forceinline__ void wg_stash(const u32x4 (&ra)[G::NLD], const u32x4 (&rg)[G::NLD], char* st, int tid) {
+__device__ __forceinline__ void wg_stash(const u32x4 (&ra)[G::NLA], const u32x4 (&rg)[G::NLG], char* st, int tid) {
 #pragma unroll
-    for (int j = 0; j < G::NLD; ++j) {
+    for (int j = 0; j < G::NLA; ++j) {
         const int i = tid + 256 * j, k = i % G::ZC, c = (i / G::ZC) % 64, p = i / (G::ZC * 64);
         const int ai = 9 * ((c >> 3) + 1) + (c & 7) + 1;
         *reinterpret_cast<u32x4*>(st + G::a_off(p, ai, k >> 2) + ((k & 3) << 4)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < G::NLG; ++j) {
+        const int i = tid + 256 * j, k = i % G::GZC, c = (i / G::GZC) % 64, p = i / (G::GZC * 64);
         *reinterpret_cast<u32x4*>(st + G::g_off(p, c, k >> 2) + ((k & 3) << 4)) = rg[j];
     }
 }
@@ -294,15 +311,15 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // the three dy-rows of one (layer, batch slice) sit 8 workgroups apart: same XCD (workgroups go round-robin over
-    // the 8 XCDs), launched together -> they share the slice's activations and gradients through that XCD's L2
-    const int b = blockIdx.x, item = (b / 24) * 8 + (b & 7), dyi = (b >> 3) % 3;
+    // the NH workgroups of one (layer, batch slice) sit 8 workgroups apart: same XCD (workgroups go round-robin over the 8
+    // XCDs), launched together -> the activations they both read meet in that XCD's L2
+    const int b = blockIdx.x, item = (b / (8 * G::NH)) * 8 + (b & 7), half = (b >> 3) % G::NH;
     if (item >= T.L * T.S) return;
-    const int l = item / T.S, split = item % T.S, dy = dyi - 1;
+    const int l = item / T.S, split = item % T.S;
     // this slice's stages (P2 positions each)
     const int stages_all = T.n / G::P2;
     const int s_begin = (int)((long long)stages_all * split / T.S), s_end = (int)((long long)stages_all * (split + 1) / T.S);
-    const int mt = w % G::MT, nt0 = (w / G::MT) * G::NTW;
+    const int mt = w % G::MT, nt0 = (w / G::MT) * G::NTW;   // C = 64: (mt, nt) = (w & 1, w >> 1); C = 128: mt = w, both N tiles
     // zero both stages' activation images once: the loads below only ever write board cells
     for (int i = tid; i < 2 * G::P2 * G::A_TILE / 16; i += 256) {
         const int st = i / (G::P2 * G::A_TILE / 16), o = i % (G::P2 * G::A_TILE / 16);
@@ -311,39 +328,35 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
     const size_t slot = (size_t)T.n * 64 * G::ZC;  // uint4 per tensor
     const u32x4* A = reinterpret_cast<const u32x4*>(T.acts) + (size_t)l * slot;
     const u32x4* Gr = reinterpret_cast<const u32x4*>(T.gs) + (size_t)l * slot;
-    constexpr int NLD = G::NLD;  // 16-byte loads per thread, tensor and stage
-    u32x4 ra[NLD], rg[NLD];
-    f32x16 acc[3][G::NTW];
+    u32x4 ra[G::NLA], rg[G::NLG];
+    f32x16 acc[9][G::NTW];
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int nt = 0; nt < G::NTW; ++nt) acc[d][nt] = (f32x16)(0.0f);
-    // the bias gradient rides along: sum over k of B[k][co] = (a fragment of ones) x B, one more MFMA per gradient
-    // fragment in the waves that hold M-tile 0 of the middle tap row (the kernel is bound by its input stream, not by
-    // the matrix pipes)
-    const bool do_bias = dyi == 1 && mt == 0;  // wave-uniform
-    f32x16 bacc[G::NTW];
+        for (int nt = 0; nt < G::NTW; ++nt) acc[t][nt] = (f32x16)(0.0f);
+    // the bias gradient rides along in the waves that hold M-tile 0: a lane's gradient fragment is 8 cells of ONE output
+    // channel, so their sum is the lane's share of that channel's column sum (one float per N tile; the two k halves of a
+    // channel leave as two partial sums)
+    const bool do_bias = mt == 0;  // wave-uniform
+    float bsum[G::NTW];
 #pragma unroll
-    for (int nt = 0; nt < G::NTW; ++nt) bacc[nt] = (f32x16)(0.0f);
-    bf16x8 ones;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    for (int nt = 0; nt < G::NTW; ++nt) bsum[nt] = 0.0f;
     // lane roles in a transpose read: group g = lane >> 4 (g >> 1 = the MFMA's k half, g & 1 = which 16 of the tile's 32
     // channels), lane 4q + pp of the group supplies cell q of the block, channels 4pp .. 4pp + 3
     const int g = lane >> 4, hh = g >> 1, cg = g & 1, q = (lane >> 2) & 3, pp = lane & 3;
     const int inner = 32 * cg + 8 * pp;
     if (s_begin >= s_end) return;  // (block-uniform; cannot happen: splits <= stages)
-    wg_fetch<G>(ra, rg, A, Gr, s_begin, tid);
+    wg_fetch<G>(ra, rg, A, Gr, s_begin, half, tid);
     __syncthreads();  // the zero fill is complete
     wg_stash<G>(ra, rg, smem, tid);
     __syncthreads();
 #pragma unroll 1
     for (int s = s_begin; s < s_end; ++s) {
         const char* st = smem + ((s - s_begin) & 1) * G::STAGE;
-        wg_fetch<G>(ra, rg, A, Gr, s + 1 < s_end ? s + 1 : s, tid);  // (the last stage re-reads itself: no branch around the registers)
+        wg_fetch<G>(ra, rg, A, Gr, s + 1 < s_end ? s + 1 : s, half, tid);  // (the last stage re-reads itself: no branch around the registers)
 #pragma unroll 1
         for (int p = 0; p < G::P2; ++p) {
-#pragma unroll
+#pragma unroll 1
             for (int kk = 0; kk < 4; ++kk) {  // k-step = board rows 2 kk (k half 0) and 2 kk + 1 (k half 1)
                 const int y = 2 * kk + hh;
                 bf16x8 bf[G::NTW];
@@ -354,35 +367,37 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
                 }
                 if (do_bias) {
 #pragma unroll
-                    for (int nt = 0; nt < G::NTW; ++nt) bacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf[nt], bacc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < G::NTW; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[nt] += (float)bf[nt][j];
                 }
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int i0 = 9 * (y + 1 + dy) + (q + d - 1) + 1, i1 = i0 + 4;
+                for (int t = 0; t < 9; ++t) {  // tap t = 3 (dy + 1) + (dx + 1): the activations one row / one column over
+                    const int i0 = 9 * (y + t / 3) + (q + t % 3 - 1) + 1, i1 = i0 + 4;
                     const bf16x8 af = tr_pair(st, G::a_off(p, i0, mt) + inner, G::a_off(p, i1, mt) + inner);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTW; ++nt) acc[d][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[d][nt], 0, 0, 0);
+                    for (int nt = 0; nt < G::NTW; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t][nt], 0, 0, 0);
                 }
             }
         }
         wg_stash<G>(ra, rg, smem + ((s + 1 - s_begin) & 1) * G::STAGE, tid);
         __syncthreads();
     }
-    // D[row = ci][col = co]: lane (r, h) register i holds ci = 32 mt + (i & 3) + 8 (i >> 2) + 4 h, co = 32 nt + r
+    // D[row = ci][col = co]: lane (r, h) register i holds ci = 32 mt + (i & 3) + 8 (i >> 2) + 4 h, co = 64 half + 32 nt + r
     const int r = lane & 31, h = lane >> 5;
-    float* P = T.partial + ((((size_t)l * 3 + dyi) * T.S + split) * 3) * C * C;
+    float* P = T.partial + (((size_t)l * T.S + split) * 9) * C * C;
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int nt = 0; nt < G::NTW; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int ci = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h, co = 32 * (nt0 + nt) + r;
-                P[((size_t)d * C + ci) * C + co] = acc[d][nt][i];
+                const int ci = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h, co = 64 * half + 32 * (nt0 + nt) + r;
+                P[((size_t)t * C + ci) * C + co] = acc[t][nt][i];
             }
-    if (do_bias && h == 0) {  // every row of the ones-product is the column sum: row 0 = register 0 of the lower lane half
+    if (do_bias) {  // lane (r, h): channel r of the tile, k half h -> partial sums [L][2 S][co]
 #pragma unroll
-        for (int nt = 0; nt < G::NTW; ++nt) T.db_partial[((size_t)l * T.S + split) * C + 32 * (nt0 + nt) + r] = bacc[nt][0];
+        for (int nt = 0; nt < G::NTW; ++nt) T.db_partial[((size_t)l * 2 * T.S + 2 * split + h) * C + 64 * half + 32 * (nt0 + nt) + r] = bsum[nt];
     }
 }
 
@@ -403,10 +418,10 @@ BZ_EXPORT int64_t bz_train_mask_bytes(int32_t C, int32_t n_layers, int32_t n) {
     if (!P || n % P) { set_error("bz_train_mask_bytes: n must be a multiple of %d for C = %d", P, C); return -1; }
     return (int64_t)n_layers * (n / P) * 256 * 16;
 }
-/* number of batch slices per (layer, tap row) of the weight-gradient kernel: 3 * n_layers * S workgroups fill the chip once */
+/* number of batch slices per layer of the weight-gradient kernel: n_layers * (C / 64) * S workgroups fill the chip once */
 BZ_EXPORT int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n) {
     if (!train_shape_ok(C, n_layers, n)) return 0;
-    int s = 256 / (3 * n_layers);
+    int s = 256 / (n_layers * (C / 64));
     const int stages = n / (256 / C);
     if (s > stages) s = stages;
     return s < 1 ? 1 : s;
@@ -460,7 +475,7 @@ BZ_EXPORT int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, in
     if (bz_device_count() <= 0) { set_error("bz_train_wgrad: no HIP device (the training kernels have no CPU path)"); return BZ_ENOGPU; }
     WgradArgs T;
     T.acts = static_cast<const __bf16*>(acts); T.gs = static_cast<const __bf16*>(gs); T.partial = partial; T.db_partial = db_partial; T.n = n; T.L = n_layers; T.S = splits;
-    const int items = n_layers * splits, grid = ((items + 7) / 8) * 24;
+    const int items = n_layers * splits, grid = ((items + 7) / 8) * 8 * (C / 64);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64) {
         static bool once = false;

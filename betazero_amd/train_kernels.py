@@ -37,8 +37,8 @@ class TowerPlan:
         self.wf_fwd = torch.zeros(nb, dtype=torch.uint8, device=dev)   # (the 2 taps of padding behind the stream stay zero)
         self.wf_bwd = torch.zeros(nb, dtype=torch.uint8, device=dev)
         self.splits = L.bz_train_wgrad_splits(channels, n_layers, batch)
-        self.partial = torch.zeros((n_layers, 3, self.splits, 3, channels, channels), dtype=torch.float32, device=dev)
-        self.db_partial = torch.zeros((n_layers, self.splits, channels), dtype=torch.float32, device=dev)
+        self.partial = torch.zeros((n_layers, self.splits, 9, channels, channels), dtype=torch.float32, device=dev)
+        self.db_partial = torch.zeros((n_layers, 2 * self.splits, channels), dtype=torch.float32, device=dev)
         self.zeros_c = torch.zeros(channels, dtype=torch.float32, device=dev)
 
     def _stream(self):
@@ -77,7 +77,8 @@ class _TowerFn(torch.autograd.Function):
                                             C, Ly, n, p.gs[0].data_ptr(), p._stream()))
             _lib.check(L.bz_train_wgrad(p.acts[0].data_ptr(), p.gs[1].data_ptr(), C, Ly, n, p.splits, p.partial.data_ptr(),
                                         p.db_partial.data_ptr(), p._stream()))
-        dW = p.partial.sum(2).permute(0, 4, 3, 1, 2).contiguous()   # [L, dy, dx, ci, co] -> torch's [L, co, ci, 3, 3]
+        # sum over the batch slices, then [L, tap, ci, co] -> torch's [L, co, ci, 3, 3]
+        dW = p.partial.sum(1).view(Ly, 3, 3, C, C).permute(0, 4, 3, 1, 2).contiguous()
         db = p.db_partial.sum(1)
         g0 = p.gs[0]
         gx0 = g0.to(ctx.in_dtype, copy=True) if ctx.nhwc else g0.view(n, 8, 8, C).permute(0, 3, 1, 2).to(ctx.in_dtype, copy=True)

@@ -358,7 +358,7 @@ int32_t bz_train_tower_fwd(const void* act0, const void* wf_fwd, const float* bi
 int32_t bz_train_tower_bwd(const void* g_top, const void* wf_bwd, const float* zeros_c, const void* masks, int32_t C,
                            int32_t n_layers, int32_t n, void* gs_out, void* stream);
 /* weight gradients: acts = act[0..L-1], gs = g[1..L], both [L][n][64][C].  partial (fp32) =
- * [L][3 dy][splits][3 dx][C ci][C co] and db_partial (fp32) = [L][splits][C]: the caller sums over `splits`
+ * [L][splits][9 taps][C ci][C co] and db_partial (fp32) = [L][2 x splits][C]: the caller sums over the second axis of both
  * (bz_train_wgrad_splits()) and permutes the former to W's layout; the latter is the bias gradient (sum of
  * g[l + 1] over positions and cells). */
 int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n);
