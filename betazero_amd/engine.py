@@ -442,14 +442,16 @@ def alloc_packed_block(na, cap_rows, device="cuda:0"):
     return t[pad:pad + total]
 
 
-def packed_block_header(block):
-    """the block's header as a dict (ONE 256-byte copy to the host when the block lives on a GPU)"""
+def packed_block_header(block, strict=True):
+    """the block's header as a dict (ONE 256-byte copy to the host when the block lives on a GPU).  strict: raise when
+    the block overflowed (rows of finished games did not fit) -- unpacking such a block would silently lose games;
+    strict=False only reports `dropped_rows` (bench.py's post-mortem of its own capacity estimate)."""
     h = block[:256].cpu().numpy().view(np.uint64)
     if int(h[0]) != PACKED_MAGIC:
         raise ValueError("not a betazero_amd packed example block (bad magic)")
     d = {"n_rows": int(h[1]), "n_games": int(h[2]), "cap_rows": int(h[3]), "na": int(h[4]), "game": int(h[5]),
          "dropped_rows": int(h[6]), "bytes": int(h[7]), "offs": [int(v) for v in h[8:16]]}
-    if d["dropped_rows"]:
+    if d["dropped_rows"] and strict:
         raise RuntimeError("packed example block overflow: " +
                            ("an engine of another geometry was appended" if d["dropped_rows"] == 2**64 - 1 else
                             f"{d['dropped_rows']} rows of finished games did not fit into cap_rows = {d['cap_rows']}"))
