@@ -3,6 +3,9 @@
 # (-DBZ_EXP_MFMA16: every 32x32x16 MFMA issued as two 16x16x32 on the same operand registers -- same MACs, same LDS and
 # weight traffic, same 8 MFMAs' worth of flops per 1-KB weight fragment; the results are wrong) against the product
 # kernel, interleaved on ONE device, plus the in-kernel clock of both from the stamped builds.  Run through gpurun.
+# (Record of the round-4 experiment, profiles/r04_ab_tower_16x16.txt: it was run while the 128-channel tower was still on
+# 32x32x16.  That tower has since MOVED to the 16x16x32 path for real -- Tw<128, 4, true> -- which -DBZ_EXP_MFMA16 does not
+# touch; the flag still applies to the geometries that kept 32x32x16, e.g. `python tools/bench_net.py` on a 64-channel net.)
 set -e
 cd "$(dirname "$0")/.."
 if [ "$FP8" = 1 ]; then  # the same question for the fp8 tower: v_mfma_scale_f32_16x16x128_f8f6f4 against 32x32x64
