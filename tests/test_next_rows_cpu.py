@@ -117,3 +117,30 @@ def test_device_examples_unpack_equals_host_unpack_on_cpu_tensors():
     both = concat_device_examples([rt, dev]).cpu()
     assert np.array_equal(both.own, np.concatenate([host.own, host.own])) and np.array_equal(both.states()[:len(host)], host.states())
     assert np.array_equal(dev.states().numpy(), host.states())
+
+
+def test_refresh_device_net_refuses_non_finite_weights():
+    """the losses of a training step are computed before its optimiser update, so a last step that overflows is invisible
+    in them; refresh_device_net must not push such weights into the engine (round 3's channels-last runs did: every later
+    search returned garbage) -- it raises, names the parameter and leaves the engine's net alone"""
+    import pytest
+    import torch
+    from betazero_amd.net import PolicyValueNet
+    from betazero_amd.train import refresh_device_net
+
+    class Net:
+        updated = False
+
+        def update(self, params):
+            self.updated = True
+    for fused in (False, True):
+        m = PolicyValueNet(32, 1, 8, fused_tower=fused)
+        dn = Net()
+        refresh_device_net(dn, m)
+        assert dn.updated
+        with torch.no_grad():
+            m.polfc.bias[3] = float("inf")
+        dn = Net()
+        with pytest.raises(FloatingPointError, match="polfc.bias"):
+            refresh_device_net(dn, m)
+        assert not dn.updated
