@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # BZ_HIP_SO: load a diagnostic variant built by betazero_amd.build.build_variant() instead of the
 # product library (needs BZ_ALLOW_EXPERIMENT=1 as well: such builds may time but not compute)
 SO = os.environ.get("BZ_HIP_SO") or os.path.join(HERE, "libbz_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
 GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3
@@ -34,6 +34,19 @@ class EngineLayout(C.Structure):
                                    "root_N", "root_W", "root_P", "leaf_own", "leaf_opp", "leaf_kind", "logits",
                                    "value", "g_own", "g_opp", "g_to_move", "g_state", "counters")] + \
                [("na", i32), ("t_max", i32)] + [(n, i64) for n in ("ex_begin", "ex_bytes", "ex_meta")]
+
+
+class TrainHeadParams(C.Structure):   # bz_train_head_params: one fp32 device pointer per head parameter tensor
+    _fields_ = [(n, vp) for n in ("pol_w", "pol_b", "polfc_w", "polfc_b", "val_w", "val_b", "v1_w", "v1_b", "v2_w", "v2_b")]
+
+
+class TrainGrads(C.Structure):        # bz_train_grads
+    _fields_ = [(n, vp) for n in ("stem_w", "stem_b", "tower_w", "tower_b", "pol_w", "pol_b", "polfc_w", "polfc_b", "val_w", "val_b",
+                                  "v1_w", "v1_b", "v2_w", "v2_b")]
+
+
+class TrainPartials(C.Structure):     # bz_train_partials
+    _fields_ = [(n, vp) for n in ("tower", "tower_b", "stem", "heads", "heads_w")] + [("splits", i32)]
 
 
 _SIGS = {
@@ -99,6 +112,12 @@ _SIGS = {
     "bz_train_tower_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "bz_train_wgrad_splits": (i32, [i32, i32, i32]),
     "bz_train_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "bz_train_ends_sizes": (i32, [i32, i32, C.POINTER(i32)]),
+    "bz_train_stem_fwd": (i32, [vp, vp, i32, vp, vp, i32, vp, vp]),
+    "bz_train_stem_wgrad": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
+    "bz_train_heads": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(TrainHeadParams), vp, vp, vp, vp, vp, vp]),
+    "bz_train_heads_wgrad": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "bz_train_finish": (i32, [C.POINTER(TrainPartials), C.POINTER(TrainGrads), i32, i32, i32, i32, vp, vp]),
     "bz_profile_enable": (i32, [i32]),
     "bz_profile_reserve": (i32, [i32, i64]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),

@@ -68,7 +68,8 @@ class GraphedTrainStep:
 
     The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
 
-    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None, lr_warmup_steps=0):
+    def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None, lr_warmup_steps=0,
+                 step_kernels=None):
         # (NCHW on purpose: channels-last convolutions measured ~20 % faster per step in tools/bench_train.py, but the
         # closed loop then failed to learn the value head in one run and produced non-finite weights in two others --
         # profiles/r03_az_loop_channels_last_failure.txt -- so that layout is not offered)
@@ -77,12 +78,20 @@ class GraphedTrainStep:
         # instead of MIOpen; default: whenever the module keeps its tower stacked (PolicyValueNet(fused_tower=True))
         if tower_kernels is None:
             tower_kernels = bool(getattr(module, "fused_tower", False))
-        self.plan = None
-        if tower_kernels:
-            from .train_kernels import TowerPlan
+        # step_kernels: the WHOLE forward / losses / backward on the HIP kernels (train_kernels.StepPlan: 9 launches, no
+        # autograd -- stem, heads and losses too); default: whenever the tower kernels are on and the step runs in bf16.
+        # step_kernels=False keeps stem / heads / losses in torch autograd around the tower kernels (the round-4 form).
+        if step_kernels is None:
+            step_kernels = tower_kernels and autocast and na == 65 and getattr(module, "VH", 65) <= 64
+        self.plan, self.step_plan = None, None
+        if tower_kernels or step_kernels:
+            from .train_kernels import StepPlan, TowerPlan
             if not getattr(module, "fused_tower", False):
-                raise ValueError("tower_kernels=True needs PolicyValueNet(..., fused_tower=True)")
-            self.plan = TowerPlan(module.C, 2 * module.NB, batch, device)
+                raise ValueError("tower_kernels / step_kernels need PolicyValueNet(..., fused_tower=True)")
+            if step_kernels:
+                self.step_plan = self.plan = StepPlan(self.module, batch, device)
+            else:
+                self.plan = TowerPlan(module.C, 2 * module.NB, batch, device)
         # lr_warmup_steps > 0: the learning rate ramps linearly from lr / warmup to lr over the first steps.  Adam's first
         # updates move every weight by ~lr whatever the gradient's size; at the loop demo's lr = 2e-3 that kills the
         # single-channel value head's ReLU (and in 2 of 4 seeds every head ReLU, i.e. the whole net) within the first
@@ -102,6 +111,10 @@ class GraphedTrainStep:
         return self.lr * min(1.0, (k + 1) / self.warmup) if self.warmup > 0 else self.lr
 
     def _step(self):
+        if self.step_plan is not None:
+            losses = self.step_plan.grads(self.own, self.opp, self.pi, self.z)   # sets every parameter's .grad
+            self.optimizer.step()
+            return losses
         x = planes_from_bits(self.own, self.opp)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.autocast):
             logits, v = self.module(x, plan=self.plan) if self.plan is not None else self.module(x)

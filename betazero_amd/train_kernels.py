@@ -9,7 +9,13 @@ so that stem, heads, losses and the optimiser stay plain torch (the loop shape o
 bf16 activations and gradients, fp32 accumulation, fp32 master weights (the kernels repack W into their bf16 fragment
 streams every step -- 2 x 147 k values per layer at C = 128).  There is no CPU path: without the HIP library or a GPU
 this raises.  PolicyValueNet uses these kernels when its forward() is handed a TowerPlan (fused_tower form); its plain
-forward() is the torch definition of the same net (CPU tests, the fp32 reference of the GPU tests)."""
+forward() is the torch definition of the same net (CPU tests, the fp32 reference of the GPU tests).
+
+StepPlan goes one further: the WHOLE step's forward, losses and backward on kernels (csrc/bz_train_ends.hip adds the stem,
+the heads with their losses, and the reduction of every partial sum into the parameters' .grad tensors) -- 9 launches,
+no autograd; only the optimiser update is torch's.  That is what GraphedTrainStep captures by default."""
+import ctypes as ct
+
 import torch
 
 from . import _lib
@@ -115,6 +121,72 @@ class _RowsLinear(torch.autograd.Function):
         # steps on this stack (all zeros here; 6e32 in the stock channels-last path -- profiles/r04_channels_last_cause.txt)
         gb = torch.bmm(gyc, gy.new_ones((ch, rows // ch, 1))).sum(0, dtype=torch.float32).squeeze(1)
         return gx, gW.to(ctx.dts[1]), gb.to(ctx.dts[2])
+
+
+class StepPlan(TowerPlan):
+    """forward + losses + backward of one training step of `module` (PolicyValueNet(fused_tower=True), on the device) at a
+    fixed batch size, entirely on the HIP kernels:
+
+        plan = StepPlan(module, batch)
+        losses = plan.grads(own, opp, pi, z)     # [loss, policy CE, value MSE] (device, static); every p.grad is set
+        optimizer.step()
+
+    own / opp: int64 tensors holding the uint64 bitboards [batch]; pi fp32 [batch, 65]; z int8 [batch].  The gradient
+    tensors are allocated once and installed as the parameters' .grad (static addresses: the step can be captured into a
+    HIP graph; do not call zero_grad(set_to_none=True) in between -- every launch overwrites them completely)."""
+
+    def __init__(self, module, batch, device="cuda:0"):
+        if not getattr(module, "fused_tower", False):
+            raise ValueError("StepPlan needs PolicyValueNet(..., fused_tower=True)")
+        if module.VH > 64:
+            raise ValueError("the head kernels hold the value head's hidden layer in one wavefront: value_hidden <= 64")
+        super().__init__(module.C, 2 * module.NB, batch, device)
+        L, dev = _lib.lib(), self.device
+        self.module, self.VH = module, module.VH
+        named = {"stem_w": module.stem.weight, "stem_b": module.stem.bias, "tower_w": module.tower_w, "tower_b": module.tower_b,
+                 "pol_w": module.pol.weight, "pol_b": module.pol.bias, "polfc_w": module.polfc.weight, "polfc_b": module.polfc.bias,
+                 "val_w": module.val.weight, "val_b": module.val.bias, "v1_w": module.v1.weight, "v1_b": module.v1.bias,
+                 "v2_w": module.v2.weight, "v2_b": module.v2.bias}
+        for k, p in named.items():
+            if p.device != dev or p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError(f"StepPlan: parameter {k} must be a contiguous fp32 tensor on {dev}")
+            p.grad = torch.zeros_like(p)
+        self.params = named
+        sizes = (ct.c_int32 * 6)()
+        _lib.check(L.bz_train_ends_sizes(self.C, batch, sizes))
+        f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+        self.stem_partial, self.heads_partial, self.heads_w_partial = f32(sizes[0], sizes[1]), f32(sizes[2], sizes[3]), f32(sizes[4], sizes[5])
+        self.hv, self.dl, self.dv1 = f32(batch, 192), f32(batch, 65), f32(batch, 64)
+        self.losses = f32(3)
+        self._head = _lib.TrainHeadParams(**{k: named[k].data_ptr() for k, _ in _lib.TrainHeadParams._fields_})
+        self._grads = _lib.TrainGrads(**{k: named[k].grad.data_ptr() for k, _ in _lib.TrainGrads._fields_})
+        self._partials = _lib.TrainPartials(tower=self.partial.data_ptr(), tower_b=self.db_partial.data_ptr(), stem=self.stem_partial.data_ptr(),
+                                            heads=self.heads_partial.data_ptr(), heads_w=self.heads_w_partial.data_ptr(), splits=self.splits)
+
+    def grads(self, own, opp, pi, z):
+        L, p, n, Cc, Ly = _lib.lib(), self.params, self.n, self.C, self.L
+        assert own.shape == (n,) and opp.shape == (n,) and own.dtype == torch.int64 and opp.dtype == torch.int64
+        assert pi.shape == (n, 65) and pi.dtype == torch.float32 and pi.is_contiguous() and z.shape == (n,) and z.dtype == torch.int8
+        for k, t in p.items():   # (an optimiser that swapped a gradient tensor out would leave the kernels writing into a dead one)
+            assert t.grad is not None and t.grad.data_ptr() == getattr(self._grads, k), f"the .grad of {k} was replaced"
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            chk = _lib.check
+            chk(L.bz_train_stem_fwd(own.data_ptr(), opp.data_ptr(), n, p["stem_w"].data_ptr(), p["stem_b"].data_ptr(), Cc, self.acts[0].data_ptr(), st))
+            chk(L.bz_train_pack_weights(p["tower_w"].data_ptr(), Cc, Ly, self.wf_fwd.data_ptr(), self.wf_bwd.data_ptr(), st))
+            chk(L.bz_train_tower_fwd(self.acts[0].data_ptr(), self.wf_fwd.data_ptr(), p["tower_b"].data_ptr(), Cc, Ly, n, self.acts[1].data_ptr(),
+                                     self.masks.data_ptr(), st))
+            chk(L.bz_train_heads(self.acts[Ly].data_ptr(), pi.data_ptr(), z.data_ptr(), n, Cc, self.VH, ct.byref(self._head), self.gs[Ly].data_ptr(),
+                                 self.hv.data_ptr(), self.dl.data_ptr(), self.dv1.data_ptr(), self.heads_partial.data_ptr(), st))
+            chk(L.bz_train_tower_bwd(self.gs[Ly].data_ptr(), self.wf_bwd.data_ptr(), self.zeros_c.data_ptr(), self.masks.data_ptr(), Cc, Ly, n,
+                                     self.gs[0].data_ptr(), st))
+            chk(L.bz_train_wgrad(self.acts[0].data_ptr(), self.gs[1].data_ptr(), Cc, Ly, n, self.splits, self.partial.data_ptr(),
+                                 self.db_partial.data_ptr(), st))
+            chk(L.bz_train_stem_wgrad(own.data_ptr(), opp.data_ptr(), self.acts[0].data_ptr(), self.gs[0].data_ptr(), n, Cc,
+                                      self.stem_partial.data_ptr(), st))
+            chk(L.bz_train_heads_wgrad(self.hv.data_ptr(), self.dl.data_ptr(), self.dv1.data_ptr(), n, self.VH, self.heads_w_partial.data_ptr(), st))
+            chk(L.bz_train_finish(ct.byref(self._partials), ct.byref(self._grads), Cc, Ly, self.VH, n, self.losses.data_ptr(), st))
+        return self.losses
 
 
 def rows_linear(x, W, b):

@@ -135,12 +135,13 @@ def test_tower_gradients_do_not_depend_on_batch_slicing_and_refuse_bad_shapes():
     assert np.isfinite(float(full.abs().sum()))
 
 
-def test_graphed_train_step_on_the_tower_kernels_tracks_the_autograd_step():
-    """GraphedTrainStep with the residual tower on the HIP kernels (forward, backward-data, backward-weights inside
-    the captured graph; stem, heads, losses and Adam in torch) against train_step through stock autograd (MIOpen) from
-    the same weights on the same batches: the same loss step by step within bf16 tolerance, and after 8 steps the
-    tower's weights have moved the same way (cosine of the two weight updates > 0.9; Adam's first steps are sign-like,
-    so tiny gradients may disagree in sign)."""
+@pytest.mark.parametrize("step_kernels", [True, False])
+def test_graphed_train_step_on_the_tower_kernels_tracks_the_autograd_step(step_kernels):
+    """GraphedTrainStep on the HIP kernels -- step_kernels=True: the whole forward / losses / backward (StepPlan, 9
+    launches, no autograd); False: the residual tower's three kernels inside torch autograd (stem, heads, losses in
+    torch) -- against train_step through stock autograd (MIOpen) from the same weights on the same batches: the same
+    loss step by step within bf16 tolerance, and after 8 steps the tower's weights have moved the same way (cosine of
+    the two weight updates > 0.9; Adam's first steps are sign-like, so tiny gradients may disagree in sign)."""
     import copy
     from betazero_amd.engine import DeviceExamples, Examples
     from betazero_amd.net import PolicyValueNet
@@ -157,8 +158,8 @@ def test_graphed_train_step_on_the_tower_kernels_tracks_the_autograd_step():
     m1 = PolicyValueNet(64, 2, 64, fused_tower=True).cuda()
     m2 = copy.deepcopy(m1)
     w0 = m1.tower_w.detach().clone()
-    g = GraphedTrainStep(m1, lr=1e-3, batch=128)
-    assert g.plan is not None  # the kernels are in the graph
+    g = GraphedTrainStep(m1, lr=1e-3, batch=128, step_kernels=step_kernels)
+    assert g.plan is not None and (g.step_plan is not None) == step_kernels  # the kernels are in the graph
     opt = make_optimizer(m2, lr=1e-3)
     gen = torch.Generator(device=DEV).manual_seed(0)
     for step in range(8):
@@ -170,3 +171,146 @@ def test_graphed_train_step_on_the_tower_kernels_tracks_the_autograd_step():
     cos = float(torch.nn.functional.cosine_similarity(d1, d2, dim=0))
     print("cosine of the tower's weight updates after 8 steps, kernels vs autograd:", round(cos, 4), "last losses", l1, l2)
     assert float(d1.abs().max()) > 0 and cos > 0.9
+    for name in ("stem", "pol", "polfc", "val", "v1", "v2"):   # the ends moved the same way too
+        a, b = getattr(m1, name).weight.detach().flatten(), getattr(m2, name).weight.detach().flatten()
+        assert float(torch.nn.functional.cosine_similarity(a, b, dim=0)) > 0.999, name
+
+
+# ---- the ends of the step (csrc/bz_train_ends.hip): each kernel alone against torch fp32 on the SAME inputs, then the whole step
+
+def _net_case(C, NB, n, seed, VH=64):
+    from betazero_amd.net import PolicyValueNet
+    from betazero_amd.train_kernels import StepPlan
+    torch.manual_seed(seed)
+    m = PolicyValueNet(C, NB, VH, fused_tower=True).cuda()
+    with torch.no_grad():   # biases away from 0 and head weights large enough that every ReLU / tanh is exercised on both sides
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.normal_(0.0, 0.2)
+        m.pol.weight.mul_(3.0); m.val.weight.mul_(3.0); m.polfc.weight.mul_(2.0)
+    rng = np.random.default_rng(seed)
+    own = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) | (rng.integers(0, 2, n).astype(np.uint64) << np.uint64(63))
+    opp = (rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) | (rng.integers(0, 2, n).astype(np.uint64) << np.uint64(63))) & ~own
+    own[0], opp[0] = np.uint64(0), np.uint64(0)                        # an empty board
+    own[1], opp[1] = np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64(0)       # a full one (bit 63 set: int64 sign)
+    pi = rng.random((n, 65)).astype(np.float32) ** 4
+    pi /= pi.sum(1, keepdims=True)
+    pi[2] = 0.0; pi[2, 64] = 1.0                                       # all mass on "pass"
+    z = rng.integers(-1, 2, n).astype(np.int8)
+    t = lambda a: torch.as_tensor(a).to(DEV)  # noqa: E731
+    return m, StepPlan(m, n), t(own.view(np.int64)), t(opp.view(np.int64)), t(pi), t(z)
+
+
+def _planes(own, opp):
+    from betazero_amd.train import planes_from_bits
+    return planes_from_bits(own, opp)
+
+
+@pytest.mark.parametrize("C,n", [(64, 8), (128, 20)])
+def test_stem_kernel_and_its_weight_gradient_vs_torch(C, n):
+    """act[0] = relu(conv3x3(planes)) straight from the bitboards: equal to torch's fp32 conv2d rounded to bf16 up to one
+    bf16 ulp (fp32 summation order); the stem's weight / bias gradient from a given g[0] equals torch autograd's of
+    sum(pre-activation * g[0] * (act[0] > 0)) to fp32 accuracy (1e-5 of the tensor's range; same bf16 inputs on both sides)."""
+    import torch.nn.functional as F
+    from betazero_amd import _lib
+    m, plan, own, opp, pi, z = _net_case(C, 1, n, 21)
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    _lib.check(L.bz_train_stem_fwd(own.data_ptr(), opp.data_ptr(), n, m.stem.weight.data_ptr(), m.stem.bias.data_ptr(), C, plan.acts[0].data_ptr(), st))
+    x = _planes(own, opp)
+    want = F.relu(F.conv2d(x, m.stem.weight, m.stem.bias, padding=1)).permute(0, 2, 3, 1).reshape(n, 64, C)
+    got = plan.acts[0].float()
+    assert float((got - want.bfloat16().float()).abs().max()) <= 2.0 ** -7 * float(want.abs().max()), "more than one bf16 ulp off"
+    assert float((got != want.bfloat16().float()).float().mean()) < 2e-3      # (and almost everywhere identical)
+    assert torch.equal(got[0], torch.relu(m.stem.bias.detach()).bfloat16().float().expand(64, C))   # the empty board: relu(bias) in every cell
+    # weight gradient
+    g0 = torch.randn((n, 64, C), device=DEV).bfloat16()
+    plan.gs[0].copy_(g0)
+    _lib.check(L.bz_train_stem_wgrad(own.data_ptr(), opp.data_ptr(), plan.acts[0].data_ptr(), plan.gs[0].data_ptr(), n, C, plan.stem_partial.data_ptr(), st))
+    _lib.check(L.bz_train_finish(_byref(plan._partials), _byref(plan._grads), C, plan.L, plan.VH, n, plan.losses.data_ptr(), st))
+    w, b = m.stem.weight.detach().clone().requires_grad_(True), m.stem.bias.detach().clone().requires_grad_(True)
+    pre = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(n, 64, C)
+    (pre * (g0.float() * (plan.acts[0] > 0))).sum().backward()
+    assert _rel(m.stem.weight.grad, w.grad) < 1e-5 and _rel(m.stem.bias.grad, b.grad) < 1e-5
+
+
+def _byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
+def _heads_reference(m, x, pi, z):
+    """heads + losses of PolicyValueNet in plain fp32 torch on act[L] given as [n, 64, C] (what net.py's forward does
+    after the tower, train.py's two losses)"""
+    import torch.nn.functional as F
+    n, C = x.shape[0], x.shape[2]
+    xc = x.view(n, 8, 8, C).permute(0, 3, 1, 2)
+    p = m.polfc(F.relu(m.pol(xc)).flatten(1))
+    v = torch.tanh(m.v2(F.relu(m.v1(F.relu(m.val(xc)).flatten(1))))).squeeze(-1)
+    ce = -(pi * F.log_softmax(p, dim=1)).sum(1).mean()
+    mse = F.mse_loss(v, z.float())
+    return ce + mse, ce, mse
+
+
+@pytest.mark.parametrize("C,n,VH", [(64, 8, 64), (128, 20, 64), (64, 1032, 24)])
+def test_heads_kernel_losses_and_gradients_vs_torch_fp32(C, n, VH):
+    """the heads kernel on a given act[L]: losses, d loss / d act[L] (times act[L] > 0, stored bf16) and the gradients of
+    all ten head parameter tensors against torch autograd in fp32 on the same bf16 activations.  fp32 on both sides:
+    1e-4 of each tensor's range (summation order); g[L] to one bf16 ulp.  n = 1032 > 4 x 256 makes workgroups take more
+    than one pass; VH = 24 leaves lanes of the value head idle."""
+    from betazero_amd import _lib
+    m, plan, own, opp, pi, z = _net_case(C, 1, n, 22, VH)
+    L, st, Ly = _lib.lib(), torch.cuda.current_stream().cuda_stream, plan.L
+    x = torch.relu(torch.randn((n, 64, C), device=DEV) - 0.3).bfloat16()
+    plan.acts[Ly].copy_(x)
+    _lib.check(L.bz_train_heads(plan.acts[Ly].data_ptr(), pi.data_ptr(), z.data_ptr(), n, C, VH, _byref(plan._head), plan.gs[Ly].data_ptr(),
+                                plan.hv.data_ptr(), plan.dl.data_ptr(), plan.dv1.data_ptr(), plan.heads_partial.data_ptr(), st))
+    _lib.check(L.bz_train_heads_wgrad(plan.hv.data_ptr(), plan.dl.data_ptr(), plan.dv1.data_ptr(), n, VH, plan.heads_w_partial.data_ptr(), st))
+    _lib.check(L.bz_train_finish(_byref(plan._partials), _byref(plan._grads), C, Ly, VH, n, plan.losses.data_ptr(), st))
+    got = {k: getattr(m, k).weight.grad.clone() for k in ("pol", "polfc", "val", "v1", "v2")}
+    gotb = {k: getattr(m, k).bias.grad.clone() for k in ("pol", "polfc", "val", "v1", "v2")}
+    losses, g_top = plan.losses.clone(), plan.gs[Ly].float().clone()
+    for p in m.parameters():
+        p.grad = None
+    xr = x.float().requires_grad_(True)
+    want = _heads_reference(m, xr, pi, z)
+    want[0].backward()
+    assert np.allclose(losses.cpu().numpy(), [float(w) for w in want], rtol=2e-5, atol=1e-6), (losses, want)
+    for k in got:
+        assert _rel(got[k], getattr(m, k).weight.grad) < 1e-4, (k, _rel(got[k], getattr(m, k).weight.grad))
+        assert _rel(gotb[k], getattr(m, k).bias.grad) < 1e-4, (k, "bias")
+    gx = xr.grad * (x > 0)
+    assert float((g_top - gx).abs().max()) <= 2.0 ** -8 * float(gx.abs().max()) + 1e-12, "g[L] more than bf16 rounding off"
+    assert float(g_top.abs().max()) > 0 and float((g_top != 0).float().mean()) > 0.05
+
+
+@pytest.mark.parametrize("C,NB,n", [(64, 2, 64), (128, 3, 32)])
+def test_whole_step_on_the_kernels_vs_torch_autograd_fp32(C, NB, n):
+    """StepPlan.grads -- stem, tower, heads, losses and every gradient on the kernels -- against autograd through the
+    plain fp32 torch forward of the same module (PolicyValueNet.forward without a plan) on the same batch: the losses
+    within 2 % (bf16 activations through the tower), every parameter's gradient within bf16 tolerance of autograd's
+    (cosine > 0.99; > 0.97 for the stem, whose gradient has passed every ReLU boundary of the tower).  This is the
+    wiring test -- each kernel's arithmetic is pinned much tighter by the tests above on equal inputs."""
+    import torch.nn.functional as F
+    m, plan, own, opp, pi, z = _net_case(C, NB, n, 23)
+    losses = plan.grads(own, opp, pi, z).clone()
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    assert set(got) == {k for k, _ in m.named_parameters()} and all(bool(torch.isfinite(g).all()) for g in got.values())
+    for p in m.parameters():
+        p.grad = None
+    logits, v = m(_planes(own, opp))
+    ce = -(pi * F.log_softmax(logits, dim=1)).sum(1).mean()
+    mse = F.mse_loss(v, z.float())
+    (ce + mse).backward()
+    want = [float(ce + mse), float(ce), float(mse)]
+    assert np.allclose(losses.cpu().numpy(), want, rtol=2e-2, atol=2e-3), (losses, want)
+    cos = {k: float(F.cosine_similarity(got[k].flatten(), p.grad.flatten(), dim=0)) for k, p in m.named_parameters() if p.numel() > 1}
+    mag = {k: float(got[k].norm() / p.grad.norm().clamp(min=1e-20)) for k, p in m.named_parameters()}
+    print("cosine of kernel vs autograd gradients:", {k: round(c, 4) for k, c in cos.items()})
+    for k, c in cos.items():
+        assert c > (0.97 if k.startswith("stem") else 0.99), (k, c)
+    # magnitudes: tensors with >= 64 elements (the 1-, 2- and 3-element bias gradients of the 1x1 convolutions are sums with
+    # heavy cancellation over cells -- 15 % off in norm at batch 64 from bf16 activations alone; the heads test above pins
+    # them to 1e-4 on equal inputs)
+    assert all(0.9 < r < 1.1 for k, r in mag.items() if got[k].numel() >= 64), mag
+    with pytest.raises(AssertionError):
+        plan.grads(own, opp, pi, z)      # ... and StepPlan notices that its gradient tensors were swapped out

@@ -29,7 +29,7 @@ ex = DeviceExamples.from_host(Examples(x & ~y, y & ~x, pi, rng.integers(-1, 2, n
                                        np.zeros(n, np.uint8), np.arange(n), np.zeros(n, np.int32), 8))
 
 
-def run(label, autocast, graph, bench, cl, kernels=False):
+def run(label, autocast, graph, bench, cl, kernels=False, step_kernels=None):
     torch.backends.cudnn.benchmark = bench
     torch.manual_seed(0)
     m = PolicyValueNet(C, NB, 64, fused_tower=kernels).cuda()
@@ -37,7 +37,7 @@ def run(label, autocast, graph, bench, cl, kernels=False):
         m = m.to(memory_format=torch.channels_last)
     idx = [torch.randint(0, n, (B,), device="cuda:0") for _ in range(8)]
     if graph:
-        g = GraphedTrainStep(m, lr=1e-3, batch=B, autocast=autocast, tower_kernels=kernels)
+        g = GraphedTrainStep(m, lr=1e-3, batch=B, autocast=autocast, tower_kernels=kernels, step_kernels=step_kernels)
         step = lambda i: g(ex, idx[i % 8])  # noqa: E731
     else:
         opt = make_optimizer(m, lr=1e-3)
@@ -87,11 +87,43 @@ def tower_only():
         print(f"  {name:14s} {ms * 1e3:8.1f} us" + ("" if name == "pack weights" else f"  {flop / (ms * 1e-3) / 1e12:7.1f} TFLOP/s"), flush=True)
 
 
+def ends_only():
+    """the kernels of csrc/bz_train_ends.hip alone, HIP events around 50 launches each"""
+    import ctypes
+    from betazero_amd import _lib
+    from betazero_amd.train_kernels import StepPlan
+    L = _lib.lib()
+    m = PolicyValueNet(C, NB, 64, fused_tower=True).cuda()
+    p = StepPlan(m, B)
+    Ly, st = p.L, torch.cuda.current_stream().cuda_stream
+    own, opp, pit, z = ex.own[:B].contiguous(), ex.opp[:B].contiguous(), ex.pi[:B].contiguous(), ex.z[:B].contiguous()
+    p.grads(own, opp, pit, z)
+    calls = {
+        "k_train_stem": lambda: L.bz_train_stem_fwd(own.data_ptr(), opp.data_ptr(), B, m.stem.weight.data_ptr(), m.stem.bias.data_ptr(), C, p.acts[0].data_ptr(), st),
+        "k_train_heads": lambda: L.bz_train_heads(p.acts[Ly].data_ptr(), pit.data_ptr(), z.data_ptr(), B, C, 64, ctypes.byref(p._head), p.gs[Ly].data_ptr(),
+                                                  p.hv.data_ptr(), p.dl.data_ptr(), p.dv1.data_ptr(), p.heads_partial.data_ptr(), st),
+        "k_train_stem_wgrad": lambda: L.bz_train_stem_wgrad(own.data_ptr(), opp.data_ptr(), p.acts[0].data_ptr(), p.gs[0].data_ptr(), B, C, p.stem_partial.data_ptr(), st),
+        "k_train_heads_wgrad": lambda: L.bz_train_heads_wgrad(p.hv.data_ptr(), p.dl.data_ptr(), p.dv1.data_ptr(), B, 64, p.heads_w_partial.data_ptr(), st),
+        "k_train_finish": lambda: L.bz_train_finish(ctypes.byref(p._partials), ctypes.byref(p._grads), C, Ly, 64, B, p.losses.data_ptr(), st)}
+    print("the ends of the step alone (csrc/bz_train_ends.hip):")
+    for name, fn in calls.items():
+        for _ in range(5):
+            _lib.check(fn())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"  {name:20s} {e0.elapsed_time(e1) / 50 * 1e3:8.1f} us", flush=True)
+
+
 print(f"net {C} channels x {NB} blocks, batch {B}")
 print("tower kernels alone (csrc/bz_train.hip):")
 tower_only()
-run("bf16 autocast graph  HIP tower kernels (bz_train.hip)", True, True, False, False, kernels=True)
-run("bf16 autocast eager  HIP tower kernels (bz_train.hip)", True, False, False, False, kernels=True) if False else None
+ends_only()
+run("bf16 graph  whole step on HIP kernels (9 launches + Adam)", True, True, False, False, kernels=True, step_kernels=True)
+run("bf16 graph  HIP tower kernels inside torch autograd", True, True, False, False, kernels=True, step_kernels=False)
 run("bf16 autocast graph  miopen-default    nchw", True, True, False, False)
 if not QUICK:
     for bench in (False, True):
