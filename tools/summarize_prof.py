@@ -5,7 +5,7 @@ SQLite) into the small files that are committed under profiles/:
                                   (the same columns as rocprofv3's own --stats CSV)
   <tag>_<name>_pmc.csv            per (kernel, counter): dispatches, mean / min / max counter value per dispatch,
                                   mean dispatch duration (ns)
-usage: python tools/summarize_prof.py r02 [--out DIR]   (default DIR = profiles/; profile_round.sh summarises on the GPU box
+usage: python tools/summarize_prof.py r02 [--out DIR] [--src DIR]   (default DIR = profiles/; profile_round.sh summarises on the GPU box
 into gpurun_out/<tag>prof/summary/ and deletes the databases, which are too big to travel back)"""
 import csv
 import glob
@@ -15,7 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = os.path.join(ROOT, "gpurun_out", f"{tag}prof")
+src = sys.argv[sys.argv.index("--src") + 1] if "--src" in sys.argv else os.path.join(ROOT, "gpurun_out", f"{tag}prof")
 dst = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
