@@ -40,9 +40,18 @@ class TrainHeadParams(C.Structure):   # bz_train_head_params: one fp32 device po
     _fields_ = [(n, vp) for n in ("pol_w", "pol_b", "polfc_w", "polfc_b", "val_w", "val_b", "v1_w", "v1_b", "v2_w", "v2_b")]
 
 
-class TrainGrads(C.Structure):        # bz_train_grads
+class TrainTensors(C.Structure):      # bz_train_tensors: one fp32 device pointer per parameter tensor (gradients / parameters / an Adam moment)
     _fields_ = [(n, vp) for n in ("stem_w", "stem_b", "tower_w", "tower_b", "pol_w", "pol_b", "polfc_w", "polfc_b", "val_w", "val_b",
                                   "v1_w", "v1_b", "v2_w", "v2_b")]
+
+
+class TrainBatch(C.Structure):        # bz_train_batch (the kernels read it from DEVICE memory)
+    _fields_ = [("own", vp), ("opp", vp), ("pi", vp), ("z", vp), ("idx", vp), ("n_rows", i64)]
+
+
+class TrainAdam(C.Structure):         # bz_train_adam
+    _fields_ = [("hyper", vp), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("p", TrainTensors), ("m", TrainTensors), ("v", TrainTensors)]
 
 
 class TrainPartials(C.Structure):     # bz_train_partials
@@ -113,11 +122,11 @@ _SIGS = {
     "bz_train_wgrad_splits": (i32, [i32, i32, i32]),
     "bz_train_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "bz_train_ends_sizes": (i32, [i32, i32, C.POINTER(i32)]),
-    "bz_train_stem_fwd": (i32, [vp, vp, i32, vp, vp, i32, vp, vp]),
-    "bz_train_stem_wgrad": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
-    "bz_train_heads": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(TrainHeadParams), vp, vp, vp, vp, vp, vp]),
+    "bz_train_stem_fwd": (i32, [vp, i32, vp, vp, i32, vp, vp]),
+    "bz_train_stem_wgrad": (i32, [vp, vp, vp, i32, i32, vp, vp]),
+    "bz_train_heads": (i32, [vp, vp, i32, i32, i32, C.POINTER(TrainHeadParams), vp, vp, vp, vp, vp, vp]),
     "bz_train_heads_wgrad": (i32, [vp, vp, vp, i32, i32, vp, vp]),
-    "bz_train_finish": (i32, [C.POINTER(TrainPartials), C.POINTER(TrainGrads), i32, i32, i32, i32, vp, vp]),
+    "bz_train_finish": (i32, [C.POINTER(TrainPartials), C.POINTER(TrainTensors), i32, i32, i32, i32, vp, C.POINTER(TrainAdam), vp]),
     "bz_profile_enable": (i32, [i32]),
     "bz_profile_reserve": (i32, [i32, i64]),
     "bz_profile_read": (i32, [i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_double)]),

@@ -67,7 +67,7 @@ __device__ __forceinline__ void store_tile(const char* buf, __bf16* dst, int pos
 template <class G, bool BWD>
 __device__ __forceinline__ void epilogue_train(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias,
                                                int wt0, int r, int h, unsigned (&bits)[4], bool use_bits) {
-    static_assert(G::MW == 1 && G::NU == 8 && G::ROWT, "the training kernels use the row-tile throughput shapes");
+    static_assert(G::MW == 1 && (G::NU == 8 || G::NU == 4), "the training kernels use one M-tile per wave and 4 or 2 positions per wave");
     const int swz = G::sw(r >> 3, r & 7);
     int home2[2] = {G::lane_home(r) + 8 * h, G::lane_home(r) + 8 * h + G::unit_imm(1)};
     asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
@@ -416,7 +416,7 @@ BZ_EXPORT int32_t bz_train_positions_per_workgroup(int32_t C) { return C == 64 ?
 BZ_EXPORT int64_t bz_train_mask_bytes(int32_t C, int32_t n_layers, int32_t n) {
     const int P = bz_train_positions_per_workgroup(C);
     if (!P || n % P) { set_error("bz_train_mask_bytes: n must be a multiple of %d for C = %d", P, C); return -1; }
-    return (int64_t)n_layers * (n / P) * 256 * 16;
+    return (int64_t)n_layers * (n / P) * 256 * 16 * (C == 64 ? 2 : 1);   // (C = 64: small batches run 4 positions per workgroup, twice the lanes)
 }
 /* number of batch slices per layer of the weight-gradient kernel: n_layers * (C / 64) * S workgroups fill the chip once */
 BZ_EXPORT int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n) {
@@ -452,7 +452,11 @@ static int32_t train_tower(bool bwd, const void* in, const void* wf, const float
         if (!once) { int32_t rc = set_lds<GEOM>(reinterpret_cast<const void*>(KERNEL<GEOM>), GEOM::LDS); if (rc != BZ_OK) return rc; once = true; } \
         hipLaunchKernelGGL(KERNEL<GEOM>, dim3(n / GEOM::P), dim3(256), GEOM::LDS, s, T);                           \
     } while (0)
-    if (C == 64) { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw<64>); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw<64>); }
+    // C = 64 keeps 8 positions per workgroup: n / 8 workgroups.  Below ~3/4 of the chip's 256 CUs, halve the tile instead
+    // (4 positions per workgroup, 2 per wave: twice the weight stream per position, but twice the CUs at work)
+    typedef Tw<64, 4> Tw64Half;
+    if (C == 64 && n / 8 < 192) { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw64Half); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw64Half); }
+    else if (C == 64) { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw<64>); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw<64>); }
     else { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw<128>); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw<128>); }
 #undef BZ_TRAIN_LAUNCH
     BZ_LAUNCH_CHECK("k_train_fwd / k_train_bwd");

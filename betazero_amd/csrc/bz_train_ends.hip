@@ -58,20 +58,31 @@ __device__ __forceinline__ unsigned nbhd_bits(unsigned long long own, unsigned l
     return m;
 }
 
+// the batch of a step: a descriptor in DEVICE memory (bz_train_batch, bz_abi.h) read at launch time, so that a captured
+// graph keeps working when the data set's tensors are replaced (the host rewrites 48 bytes).  Row of batch position p:
+// idx[p] clamped into the data set (an index out of range must not become a fault), or p itself without an index.
+__device__ __forceinline__ long long batch_row(const bz_train_batch& B, int p) {
+    long long r = B.idx ? B.idx[p] : (long long)p;
+    r = r < 0 ? 0 : r;
+    return r < B.n_rows ? r : B.n_rows - 1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // stem forward: act0[pos][cell][c] = relu(b[c] + sum_k nbhd_k * w[c][k]), k = 9 plane + tap (torch's [C][2][3][3]).
 // A workgroup takes 4 positions; a thread owns 8 channels (its 8 x 18 weights in registers) and walks the rows
 // (position, cell), so that the lanes of a row write one contiguous 16-byte piece each.
 template <int C>
-__global__ __launch_bounds__(256) void k_train_stem(const unsigned long long* __restrict__ own, const unsigned long long* __restrict__ opp,
-                                                    int n, const float* __restrict__ w, const float* __restrict__ b,
-                                                    __bf16* __restrict__ act0) {
+__global__ __launch_bounds__(256) void k_train_stem(const bz_train_batch* __restrict__ batch, int n, const float* __restrict__ w,
+                                                    const float* __restrict__ b, __bf16* __restrict__ act0) {
     constexpr int CG = C / 8, RPP = 256 / CG;
     __shared__ unsigned nb[256];
     const int tid = threadIdx.x, pos0 = blockIdx.x * 4;
     {
+        const bz_train_batch B = *batch;
         const int p = pos0 + (tid >> 6);
-        nb[tid] = p < n ? nbhd_bits(own[p], opp[p], tid & 63) : 0u;
+        unsigned m = 0u;
+        if (p < n) { const long long row = batch_row(B, p); m = nbhd_bits(B.own[row], B.opp[row], tid & 63); }
+        nb[tid] = m;
     }
     const int cg = tid % CG, rs = tid / CG;
     float wr[8][18], br[8];
@@ -108,13 +119,13 @@ __global__ __launch_bounds__(256) void k_train_stem(const unsigned long long* __
 // lane owns a channel pair (32-bit loads) and -- at C = 64 -- one of two cells per pass; 2 x 19 accumulators per lane,
 // folded across lanes / waves through LDS at the end.  partial[block][C * 18 | C]: weights in torch's layout, then biases.
 template <int C>
-__global__ __launch_bounds__(256) void k_train_stem_wgrad(const unsigned long long* __restrict__ own, const unsigned long long* __restrict__ opp,
-                                                          const unsigned* __restrict__ act0, const unsigned* __restrict__ g0, int n,
-                                                          float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void k_train_stem_wgrad(const bz_train_batch* __restrict__ batch, const unsigned* __restrict__ act0,
+                                                          const unsigned* __restrict__ g0, int n, float* __restrict__ partial) {
     constexpr int PAIRS = C / 2, CPW = 64 / PAIRS;   // lanes per cell; cells per wave pass (2 at C = 64, 1 at C = 128)
     __shared__ unsigned nb[256];
     __shared__ float red[256 * 38];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, pair = lane % PAIRS, sub = lane / PAIRS;
+    const bz_train_batch B = *batch;
     float acc[2][19];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -123,7 +134,11 @@ __global__ __launch_bounds__(256) void k_train_stem_wgrad(const unsigned long lo
     for (int grp = blockIdx.x; grp * 4 < n; grp += gridDim.x) {
         const int p = grp * 4 + wv;
         __syncthreads();
-        nb[tid] = p < n ? nbhd_bits(own[p], opp[p], lane) : 0u;
+        {
+            unsigned m = 0u;
+            if (p < n) { const long long row = batch_row(B, p); m = nbhd_bits(B.own[row], B.opp[row], lane); }
+            nb[tid] = m;
+        }
         __syncthreads();
         if (p < n) {
 #pragma unroll 4
@@ -174,8 +189,7 @@ __global__ __launch_bounds__(256) void k_train_stem_wgrad(const unsigned long lo
 // batch and are left to k_train_heads_wgrad (this kernel writes their operands h, d logit, d v1 per position).
 struct HeadArgs {
     const __bf16* x;          // act[L]  [n][64][C]
-    const float* pi;          // [n][65]
-    const signed char* z;     // [n]
+    const bz_train_batch* batch;   // pi [rows][65], z [rows] and the batch's row indices (device memory)
     int n, VH;
     float inv_n;
     const float *pol_w, *pol_b, *polfc_w, *polfc_b, *val_w, *val_b, *v1_w, *v1_b, *v2_w, *v2_b;
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
     for (int i = tid; i < 65 * 128; i += 256) Wt[(i & 127) * 65 + (i >> 7)] = A.polfc_w[i];
     for (int i = tid; i < 64 * 64; i += 256) { const int h = i >> 6, cell = i & 63; V1t[cell * 65 + h] = h < A.VH ? A.v1_w[h * 64 + cell] : 0.0f; }
     for (int i = tid; i < 3 * C; i += 256) hwS[i] = i < 2 * C ? A.pol_w[i] : A.val_w[i - 2 * C];
+    const bz_train_batch B = *A.batch;
     const float hb[3] = {A.pol_b[0], A.pol_b[1], A.val_b[0]};
     const float pfb = A.polfc_b[lane], pfb64 = A.polfc_b[64], v2b = A.v2_b[0];
     const float v1b = lane < A.VH ? A.v1_b[lane] : 0.0f, v2w = lane < A.VH ? A.v2_w[lane] : 0.0f;
@@ -226,6 +241,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
 
     for (int grp = blockIdx.x; grp * 4 < A.n; grp += gridDim.x) {   // (n is a multiple of 4: every wave of a pass has a position)
         const int pos = grp * 4 + wv;
+        const long long row = batch_row(B, pos);
         __syncthreads();   // the previous pass's copy-out has read xs; (first pass: the weight tables are in place)
         {   // x tile -> LDS, 16 bytes per lane and step, consecutive lanes consecutive addresses
             const u32x4* src = reinterpret_cast<const u32x4*>(A.x) + (size_t)pos * 64 * ZC;
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
             const float m = fmaxf(wave_max(s), l64);
             const float e = expf(s - m), e64 = expf(l64 - m);
             const float sum = wave_sum(e) + e64, lse = m + logf(sum);
-            const float pa = A.pi[(size_t)pos * 65 + lane], p64 = A.pi[(size_t)pos * 65 + 64];
+            const float pa = B.pi[(size_t)row * 65 + lane], p64 = B.pi[(size_t)row * 65 + 64];
             const float spi = wave_sum(pa) + p64;
             const float ce = -(wave_sum(pa * (s - lse)) + p64 * (l64 - lse));
             const float da = (e / sum * spi - pa) * A.inv_n, d64 = (e64 / sum * spi - p64) * A.inv_n;
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
             for (int cell = 0; cell < 64; ++cell) t = fmaf(V1t[cell * 65 + lane], hvS[128 + cell], t);
             const float v1h = fmaxf(t, 0.0f);                       // (lanes >= VH: weights and bias are zero -> 0)
             const float v = tanhf(wave_sum(v2w * v1h) + v2b);
-            const float diff = v - (float)A.z[pos];
+            const float diff = v - (float)B.z[row];
             const float dpre2 = 2.0f * diff * A.inv_n * (1.0f - v * v);
             const float dv1h = t > 0.0f ? dpre2 * v2w : 0.0f;
             dv1S[lane] = dv1h;
@@ -412,10 +428,21 @@ struct ReduceJob {
     int count, parts, stride, inner, outer_stride;   // o = hi * inner + lo  ->  src[hi * outer_stride + s * stride + lo]
     int block0;
 };
+// Adam (Kingma & Ba; torch.optim.Adam's arithmetic, no weight decay / amsgrad -- what train.py:87 constructs) on one element
+struct AdamScalars { float lr, beta1, beta2, eps, bc1, bc2_rsqrt; };   // bc1 = 1 - beta1^t, bc2_rsqrt = 1 / sqrt(1 - beta2^t)
+__device__ __forceinline__ void adam_update(float g, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t at,
+                                            const AdamScalars& a) {
+    const float mn = fmaf(a.beta1, m[at], (1.0f - a.beta1) * g);
+    const float vn = fmaf(a.beta2, v[at], (1.0f - a.beta2) * g * g);
+    m[at] = mn;
+    v[at] = vn;
+    p[at] -= (a.lr / a.bc1) * mn / (sqrtf(vn) * a.bc2_rsqrt + a.eps);
+}
 constexpr int kMaxJobs = 20;
 struct FinishArgs {
     const float* tw_partial;
     float* tw_grad;
+    float* steps_done;            // the optimiser's step counter (device; null without one): advanced here, one launch ahead of its reader
     int L, S, C, n_jobs;
     ReduceJob job[kMaxJobs];
 };
@@ -436,17 +463,18 @@ __device__ __forceinline__ float strided_sum(const float* __restrict__ p, int pa
 __global__ __launch_bounds__(256) void k_train_finish(FinishArgs F) {
     __shared__ float vals[9 * 128];
     const int tid = threadIdx.x, C = F.C;
+    if (F.steps_done && blockIdx.x == 0 && tid == 0) *F.steps_done += 1.0f;
     if ((int)blockIdx.x < F.L * C) {
         const int l = blockIdx.x / C, ci = blockIdx.x % C;
         for (int idx = tid; idx < 9 * C; idx += 256) {
-            const int t = idx / C, co = idx % C;
-            const float* p = F.tw_partial + (((size_t)l * F.S * 9 + t) * C + ci) * C + co;
+            const int tap = idx / C, co = idx % C;
+            const float* p = F.tw_partial + (((size_t)l * F.S * 9 + tap) * C + ci) * C + co;
             vals[idx] = strided_sum(p, F.S, (size_t)9 * C * C);
         }
         __syncthreads();
         for (int idx = tid; idx < 9 * C; idx += 256) {
-            const int co = idx / 9, t = idx % 9;
-            F.tw_grad[(((size_t)l * C + co) * C + ci) * 9 + t] = vals[t * C + co];
+            const int co = idx / 9, tap = idx % 9;
+            F.tw_grad[(((size_t)l * C + co) * C + ci) * 9 + tap] = vals[tap * C + co];
         }
         return;
     }
@@ -458,6 +486,38 @@ __global__ __launch_bounds__(256) void k_train_finish(FinishArgs F) {
     if (o >= J.count) return;
     const float* p = J.src + (size_t)(o / J.inner) * J.outer_stride + (o % J.inner);
     J.dst[o] = strided_sum(p, J.parts, (size_t)J.stride);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the Adam update of all 14 parameter tensors in one launch, 1024 consecutive elements per workgroup (coalesced: inside
+// k_train_finish the same update ran on the tower's transposed write pattern, 36-byte runs x 7 streams: 48 us instead of 6).
+// hyper (device): {learning rate, step number t, warm-up steps}; the rate is lr * min(1, t / warm-up).  t is advanced by
+// k_train_finish, the launch before this one: a counter advanced HERE needs a last-workgroup ticket -- one device-scope
+// atomic and fence per workgroup on one address, which serialised the 1728 workgroups of the 128-channel net to 64 us.
+struct AdamJob { float *p, *m, *v; const float* g; int count, block0; };
+struct AdamArgs {
+    const float* hyper;
+    float beta1, beta2, eps;
+    int n_jobs;
+    AdamJob job[14];
+};
+__global__ __launch_bounds__(256) void k_train_adam(AdamArgs A) {
+    const int tid = threadIdx.x;
+    const float t = A.hyper[1], warm = A.hyper[2];
+    AdamScalars ad;
+    ad.lr = warm > 0.0f ? A.hyper[0] * fminf(1.0f, t / warm) : A.hyper[0];
+    ad.beta1 = A.beta1; ad.beta2 = A.beta2; ad.eps = A.eps;
+    ad.bc1 = 1.0f - powf(A.beta1, t);
+    ad.bc2_rsqrt = 1.0f / sqrtf(1.0f - powf(A.beta2, t));
+    int j = 0;
+    while (j + 1 < A.n_jobs && (int)blockIdx.x >= A.job[j + 1].block0) ++j;
+    const AdamJob J = A.job[j];
+    const int base = ((int)blockIdx.x - J.block0) * 1024;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = base + 256 * e + tid;
+        if (o < J.count) adam_update(J.g[o], J.p, J.m, J.v, (size_t)o, ad);
+    }
 }
 
 bool ends_shape_ok(int C, int n) { return (C == 64 || C == 128) && n >= 4 && n % 4 == 0; }
@@ -476,37 +536,37 @@ BZ_EXPORT int32_t bz_train_ends_sizes(int32_t C, int32_t n, int32_t* sizes) {
     return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_train_stem_fwd(const uint64_t* own, const uint64_t* opp, int32_t n, const float* stem_w, const float* stem_b, int32_t C,
-                                    void* act0, void* stream) {
-    BZ_REQUIRE(own && opp && stem_w && stem_b && act0 && ends_shape_ok(C, n), "bz_train_stem_fwd: bad arguments (C = 64 or 128, n a multiple of 4)");
+BZ_EXPORT int32_t bz_train_stem_fwd(const bz_train_batch* batch_dev, int32_t n, const float* stem_w, const float* stem_b, int32_t C, void* act0,
+                                    void* stream) {
+    BZ_REQUIRE(batch_dev && stem_w && stem_b && act0 && ends_shape_ok(C, n), "bz_train_stem_fwd: bad arguments (C = 64 or 128, n a multiple of 4)");
     if (bz_device_count() <= 0) { set_error("bz_train_stem_fwd: no HIP device (the training kernels have no CPU path)"); return BZ_ENOGPU; }
     const dim3 grid((n + 3) / 4);
-    if (C == 64) hipLaunchKernelGGL(k_train_stem<64>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)own, (const unsigned long long*)opp, n, stem_w, stem_b, static_cast<__bf16*>(act0));
-    else hipLaunchKernelGGL(k_train_stem<128>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)own, (const unsigned long long*)opp, n, stem_w, stem_b, static_cast<__bf16*>(act0));
+    if (C == 64) hipLaunchKernelGGL(k_train_stem<64>, grid, dim3(256), 0, (hipStream_t)stream, batch_dev, n, stem_w, stem_b, static_cast<__bf16*>(act0));
+    else hipLaunchKernelGGL(k_train_stem<128>, grid, dim3(256), 0, (hipStream_t)stream, batch_dev, n, stem_w, stem_b, static_cast<__bf16*>(act0));
     BZ_LAUNCH_CHECK("k_train_stem");
     return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_train_stem_wgrad(const uint64_t* own, const uint64_t* opp, const void* act0, const void* g0, int32_t n, int32_t C,
-                                      float* partial, void* stream) {
-    BZ_REQUIRE(own && opp && act0 && g0 && partial && ends_shape_ok(C, n), "bz_train_stem_wgrad: bad arguments (C = 64 or 128, n a multiple of 4)");
+BZ_EXPORT int32_t bz_train_stem_wgrad(const bz_train_batch* batch_dev, const void* act0, const void* g0, int32_t n, int32_t C, float* partial,
+                                      void* stream) {
+    BZ_REQUIRE(batch_dev && act0 && g0 && partial && ends_shape_ok(C, n), "bz_train_stem_wgrad: bad arguments (C = 64 or 128, n a multiple of 4)");
     if (bz_device_count() <= 0) { set_error("bz_train_stem_wgrad: no HIP device (the training kernels have no CPU path)"); return BZ_ENOGPU; }
     const dim3 grid(stem_blocks(n));
-    if (C == 64) hipLaunchKernelGGL(k_train_stem_wgrad<64>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)own, (const unsigned long long*)opp, static_cast<const unsigned*>(act0), static_cast<const unsigned*>(g0), n, partial);
-    else hipLaunchKernelGGL(k_train_stem_wgrad<128>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)own, (const unsigned long long*)opp, static_cast<const unsigned*>(act0), static_cast<const unsigned*>(g0), n, partial);
+    if (C == 64) hipLaunchKernelGGL(k_train_stem_wgrad<64>, grid, dim3(256), 0, (hipStream_t)stream, batch_dev, static_cast<const unsigned*>(act0), static_cast<const unsigned*>(g0), n, partial);
+    else hipLaunchKernelGGL(k_train_stem_wgrad<128>, grid, dim3(256), 0, (hipStream_t)stream, batch_dev, static_cast<const unsigned*>(act0), static_cast<const unsigned*>(g0), n, partial);
     BZ_LAUNCH_CHECK("k_train_stem_wgrad");
     return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_train_heads(const void* act_top, const float* pi, const int8_t* z, int32_t n, int32_t C, int32_t VH,
+BZ_EXPORT int32_t bz_train_heads(const void* act_top, const bz_train_batch* batch_dev, int32_t n, int32_t C, int32_t VH,
                                  const bz_train_head_params* P, void* g_top, float* hv, float* dl, float* dv1, float* partial, void* stream) {
-    BZ_REQUIRE(act_top && pi && z && P && g_top && hv && dl && dv1 && partial && ends_shape_ok(C, n) && VH >= 1 && VH <= 64,
+    BZ_REQUIRE(act_top && batch_dev && P && g_top && hv && dl && dv1 && partial && ends_shape_ok(C, n) && VH >= 1 && VH <= 64,
                "bz_train_heads: bad arguments (C = 64 or 128, n a multiple of 4, value_hidden <= 64)");
     BZ_REQUIRE(P->pol_w && P->pol_b && P->polfc_w && P->polfc_b && P->val_w && P->val_b && P->v1_w && P->v1_b && P->v2_w && P->v2_b,
                "bz_train_heads: a head parameter pointer is null");
     if (bz_device_count() <= 0) { set_error("bz_train_heads: no HIP device (the training kernels have no CPU path)"); return BZ_ENOGPU; }
     HeadArgs A;
-    A.x = static_cast<const __bf16*>(act_top); A.pi = pi; A.z = reinterpret_cast<const signed char*>(z); A.n = n; A.VH = VH; A.inv_n = 1.0f / (float)n;
+    A.x = static_cast<const __bf16*>(act_top); A.batch = batch_dev; A.n = n; A.VH = VH; A.inv_n = 1.0f / (float)n;
     A.pol_w = P->pol_w; A.pol_b = P->pol_b; A.polfc_w = P->polfc_w; A.polfc_b = P->polfc_b; A.val_w = P->val_w; A.val_b = P->val_b;
     A.v1_w = P->v1_w; A.v1_b = P->v1_b; A.v2_w = P->v2_w; A.v2_b = P->v2_b;
     A.g_top = static_cast<__bf16*>(g_top); A.hv = hv; A.dl = dl; A.dv1 = dv1; A.partial = partial;
@@ -533,37 +593,67 @@ BZ_EXPORT int32_t bz_train_heads_wgrad(const float* hv, const float* dl, const f
     return BZ_OK;
 }
 
-BZ_EXPORT int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_grads* G, int32_t C, int32_t n_layers, int32_t VH, int32_t n,
-                                  float* losses, void* stream) {
+namespace {
+bool all_set(const bz_train_tensors* T) {
+    return T->stem_w && T->stem_b && T->tower_w && T->tower_b && T->pol_w && T->pol_b && T->polfc_w && T->polfc_b && T->val_w && T->val_b &&
+           T->v1_w && T->v1_b && T->v2_w && T->v2_b;
+}
+}  // namespace
+
+BZ_EXPORT int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_tensors* G, int32_t C, int32_t n_layers, int32_t VH, int32_t n,
+                                  float* losses, const bz_train_adam* opt, void* stream) {
     BZ_REQUIRE(Q && G && losses && ends_shape_ok(C, n) && n_layers >= 2 && VH >= 1 && VH <= 64, "bz_train_finish: bad arguments");
     BZ_REQUIRE(Q->tower && Q->tower_b && Q->stem && Q->heads && Q->heads_w && Q->splits >= 1, "bz_train_finish: a partial-sum pointer is null");
-    BZ_REQUIRE(G->stem_w && G->stem_b && G->tower_w && G->tower_b && G->pol_w && G->pol_b && G->polfc_w && G->polfc_b && G->val_w && G->val_b &&
-               G->v1_w && G->v1_b && G->v2_w && G->v2_b, "bz_train_finish: a gradient pointer is null");
+    BZ_REQUIRE(all_set(G), "bz_train_finish: a gradient pointer is null");
+    if (opt) {
+        BZ_REQUIRE(opt->hyper && all_set(&opt->p) && all_set(&opt->m) && all_set(&opt->v), "bz_train_finish: the optimiser block has a null pointer");
+        BZ_REQUIRE(opt->beta1 >= 0.0f && opt->beta1 < 1.0f && opt->beta2 >= 0.0f && opt->beta2 < 1.0f && opt->eps > 0.0f,
+                   "bz_train_finish: Adam needs 0 <= beta < 1 and eps > 0");
+    }
     if (bz_device_count() <= 0) { set_error("bz_train_finish: no HIP device (the training kernels have no CPU path)"); return BZ_ENOGPU; }
     FinishArgs F;
     F.tw_partial = Q->tower; F.tw_grad = G->tower_w; F.L = n_layers; F.S = Q->splits; F.C = C; F.n_jobs = 0;
+    F.steps_done = opt ? opt->hyper + 1 : nullptr;
     int next_block = 0;
-    auto add = [&](const float* src, float* dst, int count, int parts, int stride, int inner, int outer_stride) {
+    // field = the tensor's slot in bz_train_tensors (null for the three loss values)
+    auto add = [&](const float* src, float* bz_train_tensors::*field, float* dst_plain, int count, int parts, int stride, int inner, int outer_stride) {
         ReduceJob& J = F.job[F.n_jobs++];
-        J.src = src; J.dst = dst; J.count = count; J.parts = parts; J.stride = stride; J.inner = inner; J.outer_stride = outer_stride; J.block0 = next_block;
+        J.src = src; J.dst = field ? G->*field : dst_plain;
+        J.count = count; J.parts = parts; J.stride = stride; J.inner = inner; J.outer_stride = outer_stride; J.block0 = next_block;
         next_block += (count + 255) / 256;
     };
+    typedef bz_train_tensors T;
     const int nS = stem_blocks(n), nH = heads_blocks(n), nW = heads_w_blocks(n), NP = 3 * C + 200;
-    add(Q->tower_b, G->tower_b, n_layers * C, 2 * Q->splits, C, C, 2 * Q->splits * C);
-    add(Q->stem, G->stem_w, C * 18, nS, C * 19, C * 18, 0);
-    add(Q->stem + C * 18, G->stem_b, C, nS, C * 19, C, 0);
-    add(Q->heads, G->pol_w, 2 * C, nH, NP, 2 * C, 0);
-    add(Q->heads + 2 * C, G->val_w, C, nH, NP, C, 0);
-    add(Q->heads + 3 * C, G->pol_b, 2, nH, NP, 2, 0);
-    add(Q->heads + 3 * C + 2, G->val_b, 1, nH, NP, 1, 0);
-    add(Q->heads + 3 * C + 3, G->polfc_b, 65, nH, NP, 65, 0);
-    add(Q->heads + 3 * C + 68, G->v1_b, VH, nH, NP, VH, 0);
-    add(Q->heads + 3 * C + 132, G->v2_w, VH, nH, NP, VH, 0);
-    add(Q->heads + 3 * C + 196, G->v2_b, 1, nH, NP, 1, 0);
-    add(Q->heads + 3 * C + 197, losses, 3, nH, NP, 3, 0);
-    add(Q->heads_w, G->polfc_w, 65 * 128, nW, kHeadWOut, 65 * 128, 0);
-    add(Q->heads_w + 65 * 128, G->v1_w, VH * 64, nW, kHeadWOut, VH * 64, 0);
+    add(Q->tower_b, &T::tower_b, nullptr, n_layers * C, 2 * Q->splits, C, C, 2 * Q->splits * C);
+    add(Q->stem, &T::stem_w, nullptr, C * 18, nS, C * 19, C * 18, 0);
+    add(Q->stem + C * 18, &T::stem_b, nullptr, C, nS, C * 19, C, 0);
+    add(Q->heads, &T::pol_w, nullptr, 2 * C, nH, NP, 2 * C, 0);
+    add(Q->heads + 2 * C, &T::val_w, nullptr, C, nH, NP, C, 0);
+    add(Q->heads + 3 * C, &T::pol_b, nullptr, 2, nH, NP, 2, 0);
+    add(Q->heads + 3 * C + 2, &T::val_b, nullptr, 1, nH, NP, 1, 0);
+    add(Q->heads + 3 * C + 3, &T::polfc_b, nullptr, 65, nH, NP, 65, 0);
+    add(Q->heads + 3 * C + 68, &T::v1_b, nullptr, VH, nH, NP, VH, 0);
+    add(Q->heads + 3 * C + 132, &T::v2_w, nullptr, VH, nH, NP, VH, 0);
+    add(Q->heads + 3 * C + 196, &T::v2_b, nullptr, 1, nH, NP, 1, 0);
+    add(Q->heads + 3 * C + 197, nullptr, losses, 3, nH, NP, 3, 0);
+    add(Q->heads_w, &T::polfc_w, nullptr, 65 * 128, nW, kHeadWOut, 65 * 128, 0);
+    add(Q->heads_w + 65 * 128, &T::v1_w, nullptr, VH * 64, nW, kHeadWOut, VH * 64, 0);
     hipLaunchKernelGGL(k_train_finish, dim3(n_layers * C + next_block), dim3(256), 0, (hipStream_t)stream, F);
     BZ_LAUNCH_CHECK("k_train_finish");
+    if (opt) {
+        AdamArgs A;
+        A.hyper = opt->hyper; A.beta1 = opt->beta1; A.beta2 = opt->beta2; A.eps = opt->eps; A.n_jobs = 0;
+        int blocks = 0;
+        auto adam = [&](float* bz_train_tensors::*field, int count) {
+            AdamJob& J = A.job[A.n_jobs++];
+            J.p = opt->p.*field; J.m = opt->m.*field; J.v = opt->v.*field; J.g = G->*field; J.count = count; J.block0 = blocks;
+            blocks += (count + 1023) / 1024;
+        };
+        adam(&T::tower_w, n_layers * C * C * 9); adam(&T::tower_b, n_layers * C); adam(&T::stem_w, C * 18); adam(&T::stem_b, C);
+        adam(&T::pol_w, 2 * C); adam(&T::pol_b, 2); adam(&T::polfc_w, 65 * 128); adam(&T::polfc_b, 65); adam(&T::val_w, C); adam(&T::val_b, 1);
+        adam(&T::v1_w, VH * 64); adam(&T::v1_b, VH); adam(&T::v2_w, VH); adam(&T::v2_b, 1);
+        hipLaunchKernelGGL(k_train_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A);
+        BZ_LAUNCH_CHECK("k_train_adam");
+    }
     return BZ_OK;
 }

@@ -69,7 +69,7 @@ class GraphedTrainStep:
     The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
 
     def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None, lr_warmup_steps=0,
-                 step_kernels=None):
+                 step_kernels=None, fused_adam=None):
         # (NCHW on purpose: channels-last convolutions measured ~20 % faster per step in tools/bench_train.py, but the
         # closed loop then failed to learn the value head in one run and produced non-finite weights in two others --
         # profiles/r03_az_loop_channels_last_failure.txt -- so that layout is not offered)
@@ -90,6 +90,7 @@ class GraphedTrainStep:
                 raise ValueError("tower_kernels / step_kernels need PolicyValueNet(..., fused_tower=True)")
             if step_kernels:
                 self.step_plan = self.plan = StepPlan(self.module, batch, device)
+                self.idx = torch.zeros(batch, dtype=torch.int64, device=self.dev)   # the batch's rows: the kernels gather them themselves
             else:
                 self.plan = TowerPlan(module.C, 2 * module.NB, batch, device)
         # lr_warmup_steps > 0: the learning rate ramps linearly from lr / warmup to lr over the first steps.  Adam's first
@@ -99,8 +100,17 @@ class GraphedTrainStep:
         # scalar (capturable Adam reads it inside the graph) that __call__ sets before each replay.
         self.lr, self.warmup, self.steps_done = float(lr), int(lr_warmup_steps), 0
         self.lr_t = torch.tensor(self._lr_at(0), dtype=torch.float32, device=self.dev)
+        # fused_adam (default with step_kernels): the Adam update as the step's tenth kernel (StepPlan.enable_adam: step count
+        # and warm-up live on the device; a step is then ONE graph launch and a copy of the batch's row numbers).  Otherwise torch's:
         # (fused: the whole Adam update of all parameter tensors is one kernel instead of ~10 multi-tensor ones)
-        self.optimizer = torch.optim.Adam(module.parameters(), lr=self.lr_t, capturable=True, fused=True)
+        self.fused_adam = bool(self.step_plan is not None) if fused_adam is None else bool(fused_adam)
+        if self.fused_adam:
+            if self.step_plan is None:
+                raise ValueError("fused_adam needs step_kernels")
+            self.step_plan.enable_adam(self.lr, warmup_steps=self.warmup)
+            self.optimizer = None
+        else:
+            self.optimizer = torch.optim.Adam(module.parameters(), lr=self.lr_t, capturable=True, fused=True)
         self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.pi = torch.full((batch, na), 1.0 / na, dtype=torch.float32, device=self.dev)
@@ -112,7 +122,9 @@ class GraphedTrainStep:
 
     def _step(self):
         if self.step_plan is not None:
-            losses = self.step_plan.grads(self.own, self.opp, self.pi, self.z)   # sets every parameter's .grad
+            if self.fused_adam:
+                return self.step_plan.step()           # 10 launches: gradients and the Adam update
+            losses = self.step_plan.grads()            # sets every parameter's .grad
             self.optimizer.step()
             return losses
         x = planes_from_bits(self.own, self.opp)
@@ -133,29 +145,39 @@ class GraphedTrainStep:
         afterwards; then the capture (which launches nothing: the first real step is the first replay)"""
         self.module.train()
         self.lr_t.zero_()
+        if self.fused_adam:
+            self.step_plan.set_lr(0.0)
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side):
             for _ in range(3):
                 self._step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        for st in self.optimizer.state.values():  # the warm-up must not count as steps / leave moments behind
-            for k, v in st.items():
-                if torch.is_tensor(v):
-                    v.zero_()
+        if self.fused_adam:   # the warm-up must not count as steps / leave moments behind
+            self.step_plan.reset_adam(self.lr, self.warmup, steps_done=self.steps_done)
+        else:
+            for st in self.optimizer.state.values():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.zero_()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._step()
 
     def __call__(self, ex, idx):
         assert idx.numel() == self.batch, "GraphedTrainStep replays a fixed batch size"
-        torch.index_select(ex.own, 0, idx, out=self.own)
-        torch.index_select(ex.opp, 0, idx, out=self.opp)
-        torch.index_select(ex.pi, 0, idx, out=self.pi)
-        torch.index_select(ex.z, 0, idx, out=self.z)
+        if self.step_plan is not None:   # the kernels read rows idx of the data set themselves: one 8-byte-per-row copy, no gathers
+            self.idx.copy_(idx)
+            self.step_plan.set_batch(ex.own, ex.opp, ex.pi, ex.z, self.idx)
+        else:
+            torch.index_select(ex.own, 0, idx, out=self.own)
+            torch.index_select(ex.opp, 0, idx, out=self.opp)
+            torch.index_select(ex.pi, 0, idx, out=self.pi)
+            torch.index_select(ex.z, 0, idx, out=self.z)
         if self.graph is None:
             self._capture()
-        self.lr_t.fill_(self._lr_at(self.steps_done))
+        if not self.fused_adam:
+            self.lr_t.fill_(self._lr_at(self.steps_done))
         self.graph.replay()
         self.steps_done += 1
         return self.out.clone()

@@ -124,16 +124,22 @@ class _RowsLinear(torch.autograd.Function):
 
 
 class StepPlan(TowerPlan):
-    """forward + losses + backward of one training step of `module` (PolicyValueNet(fused_tower=True), on the device) at a
-    fixed batch size, entirely on the HIP kernels:
+    """forward + losses + backward (+ Adam) of one training step of `module` (PolicyValueNet(fused_tower=True), on the
+    device) at a fixed batch size, entirely on the HIP kernels:
 
         plan = StepPlan(module, batch)
-        losses = plan.grads(own, opp, pi, z)     # [loss, policy CE, value MSE] (device, static); every p.grad is set
-        optimizer.step()
+        plan.set_batch(own, opp, pi, z, idx)     # the data set's tensors and the batch's row indices (idx None: rows 0..batch-1)
+        losses = plan.grads()                    # [loss, policy CE, value MSE] (device, static); every p.grad is set
+        optimizer.step()                         # torch's -- or instead of the two lines above:
+        plan.enable_adam(lr); losses = plan.step()    # + the Adam update as a tenth launch (torch.optim.Adam's arithmetic)
 
-    own / opp: int64 tensors holding the uint64 bitboards [batch]; pi fp32 [batch, 65]; z int8 [batch].  The gradient
-    tensors are allocated once and installed as the parameters' .grad (static addresses: the step can be captured into a
-    HIP graph; do not call zero_grad(set_to_none=True) in between -- every launch overwrites them completely)."""
+    own / opp: int64 tensors holding the uint64 bitboards [rows]; pi fp32 [rows, 65]; z int8 [rows]; idx int64 [batch].
+    The kernels read the batch through a 48-byte descriptor in device memory (bz_train_batch) and gather the rows
+    themselves: a captured step keeps working when set_batch() points it at new tensors -- nothing is copied.  The
+    gradient tensors are allocated once and installed as the parameters' .grad (static addresses: the step can be
+    captured into a HIP graph; do not call zero_grad(set_to_none=True) in between -- every launch overwrites them)."""
+
+    NAMES = ("stem_w", "stem_b", "tower_w", "tower_b", "pol_w", "pol_b", "polfc_w", "polfc_b", "val_w", "val_b", "v1_w", "v1_b", "v2_w", "v2_b")
 
     def __init__(self, module, batch, device="cuda:0"):
         if not getattr(module, "fused_tower", False):
@@ -159,34 +165,115 @@ class StepPlan(TowerPlan):
         self.hv, self.dl, self.dv1 = f32(batch, 192), f32(batch, 65), f32(batch, 64)
         self.losses = f32(3)
         self._head = _lib.TrainHeadParams(**{k: named[k].data_ptr() for k, _ in _lib.TrainHeadParams._fields_})
-        self._grads = _lib.TrainGrads(**{k: named[k].grad.data_ptr() for k, _ in _lib.TrainGrads._fields_})
+        self._grads = _lib.TrainTensors(**{k: named[k].grad.data_ptr() for k in self.NAMES})
         self._partials = _lib.TrainPartials(tower=self.partial.data_ptr(), tower_b=self.db_partial.data_ptr(), stem=self.stem_partial.data_ptr(),
                                             heads=self.heads_partial.data_ptr(), heads_w=self.heads_w_partial.data_ptr(), splits=self.splits)
+        self.batch_desc = torch.zeros(ct.sizeof(_lib.TrainBatch), dtype=torch.uint8, device=dev)
+        self._batch_refs = None
+        self._adam, self.adam_m, self.adam_v, self.hyper = None, None, None, None
 
-    def grads(self, own, opp, pi, z):
+    # ---- the batch
+    def set_batch(self, own, opp, pi, z, idx=None):
+        """point the step at rows `idx` (int64 [batch], on the device; None: rows 0..batch-1) of the data set (own, opp, pi,
+        z).  Asynchronous on the current stream; the tensors are kept alive until the next call."""
+        n, dev = self.n, self.device
+        rows = int(own.shape[0])
+        ok = (own.dtype == torch.int64 and opp.dtype == torch.int64 and own.shape == (rows,) and opp.shape == (rows,) and
+              pi.dtype == torch.float32 and pi.shape == (rows, 65) and z.dtype == torch.int8 and z.shape == (rows,) and
+              all(t.is_contiguous() and t.device == dev for t in (own, opp, pi, z)))
+        if not ok:
+            raise ValueError("set_batch: own / opp int64 [rows], pi fp32 [rows, 65], z int8 [rows], contiguous, on the plan's device")
+        if idx is None:
+            if rows < n:
+                raise ValueError(f"set_batch: the data set has {rows} rows, the batch needs {n}")
+        elif not (idx.dtype == torch.int64 and idx.shape == (n,) and idx.is_contiguous() and idx.device == dev):
+            raise ValueError(f"set_batch: idx must be a contiguous int64 tensor of {n} row numbers on the plan's device")
+        d = _lib.TrainBatch(own=own.data_ptr(), opp=opp.data_ptr(), pi=pi.data_ptr(), z=z.data_ptr(),
+                            idx=idx.data_ptr() if idx is not None else None, n_rows=rows)
+        key = bytes(d)
+        if self._batch_refs is None or self._batch_refs[0] != key:   # (a pageable host copy: ordered on the current stream, done on return)
+            with torch.cuda.device(dev):
+                self.batch_desc.copy_(torch.frombuffer(bytearray(key), dtype=torch.uint8))
+        self._batch_refs = (key, own, opp, pi, z, idx)
+
+    # ---- the optimiser as the step's tenth launch
+    def enable_adam(self, lr, betas=(0.9, 0.999), eps=1e-8, warmup_steps=0):
+        """Adam (torch.optim.Adam's arithmetic, no weight decay / amsgrad: what the reference constructs, train.py:87) applied
+        by k_train_adam right behind k_train_finish (one coalesced pass over all 14 tensors).  State: adam_m / adam_v (dicts of tensors like the parameters) and
+        the device block `hyper` = {lr, steps done, warm-up steps, 0}: the kernel advances the step count itself and ramps
+        the rate over the first warmup_steps steps (lr * min(1, t / warmup_steps)), so consecutive steps need no host write."""
+        self.adam_m = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        self.adam_v = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
+        T = _lib.TrainTensors
+        self._adam = _lib.TrainAdam(hyper=self.hyper.data_ptr(), beta1=betas[0], beta2=betas[1], eps=eps,
+                                    p=T(**{k: self.params[k].data_ptr() for k in self.NAMES}),
+                                    m=T(**{k: self.adam_m[k].data_ptr() for k in self.NAMES}),
+                                    v=T(**{k: self.adam_v[k].data_ptr() for k in self.NAMES}))
+        self.reset_adam(lr, warmup_steps)
+
+    def reset_adam(self, lr=None, warmup_steps=None, steps_done=0):
+        """zero moments, step count `steps_done`, (new) rate / warm-up"""
+        if lr is not None:
+            self.lr = float(lr)
+        if warmup_steps is not None:
+            self.warmup = int(warmup_steps)
+        for d in (self.adam_m, self.adam_v):
+            for t in d.values():
+                t.zero_()
+        with torch.cuda.device(self.device):
+            self.hyper.copy_(torch.tensor([self.lr, float(steps_done), float(self.warmup), 0.0], dtype=torch.float32))
+
+    def set_lr(self, lr):
+        """change the (peak) learning rate; moments and step count stay"""
+        self.lr = float(lr)
+        with torch.cuda.device(self.device):
+            self.hyper[0:1].copy_(torch.tensor([self.lr], dtype=torch.float32))
+
+    @property
+    def adam_t(self):
+        """steps done so far (reads the device counter: synchronises)"""
+        return int(self.hyper[1].item()) if self.hyper is not None else 0
+
+    # ---- the launches
+    def launch(self, adam=False):
+        """the 9 (adam: 10) launches of one step on the current stream (no host work besides: this is what a HIP graph captures)"""
         L, p, n, Cc, Ly = _lib.lib(), self.params, self.n, self.C, self.L
-        assert own.shape == (n,) and opp.shape == (n,) and own.dtype == torch.int64 and opp.dtype == torch.int64
-        assert pi.shape == (n, 65) and pi.dtype == torch.float32 and pi.is_contiguous() and z.shape == (n,) and z.dtype == torch.int8
+        if self._batch_refs is None:
+            raise RuntimeError("StepPlan: set_batch() first")
+        if adam and self._adam is None:
+            raise RuntimeError("StepPlan: enable_adam() first")
         for k, t in p.items():   # (an optimiser that swapped a gradient tensor out would leave the kernels writing into a dead one)
             assert t.grad is not None and t.grad.data_ptr() == getattr(self._grads, k), f"the .grad of {k} was replaced"
         with torch.cuda.device(self.device):
-            st = self._stream()
+            st, bd = self._stream(), self.batch_desc.data_ptr()
             chk = _lib.check
-            chk(L.bz_train_stem_fwd(own.data_ptr(), opp.data_ptr(), n, p["stem_w"].data_ptr(), p["stem_b"].data_ptr(), Cc, self.acts[0].data_ptr(), st))
+            chk(L.bz_train_stem_fwd(bd, n, p["stem_w"].data_ptr(), p["stem_b"].data_ptr(), Cc, self.acts[0].data_ptr(), st))
             chk(L.bz_train_pack_weights(p["tower_w"].data_ptr(), Cc, Ly, self.wf_fwd.data_ptr(), self.wf_bwd.data_ptr(), st))
             chk(L.bz_train_tower_fwd(self.acts[0].data_ptr(), self.wf_fwd.data_ptr(), p["tower_b"].data_ptr(), Cc, Ly, n, self.acts[1].data_ptr(),
                                      self.masks.data_ptr(), st))
-            chk(L.bz_train_heads(self.acts[Ly].data_ptr(), pi.data_ptr(), z.data_ptr(), n, Cc, self.VH, ct.byref(self._head), self.gs[Ly].data_ptr(),
+            chk(L.bz_train_heads(self.acts[Ly].data_ptr(), bd, n, Cc, self.VH, ct.byref(self._head), self.gs[Ly].data_ptr(),
                                  self.hv.data_ptr(), self.dl.data_ptr(), self.dv1.data_ptr(), self.heads_partial.data_ptr(), st))
             chk(L.bz_train_tower_bwd(self.gs[Ly].data_ptr(), self.wf_bwd.data_ptr(), self.zeros_c.data_ptr(), self.masks.data_ptr(), Cc, Ly, n,
                                      self.gs[0].data_ptr(), st))
             chk(L.bz_train_wgrad(self.acts[0].data_ptr(), self.gs[1].data_ptr(), Cc, Ly, n, self.splits, self.partial.data_ptr(),
                                  self.db_partial.data_ptr(), st))
-            chk(L.bz_train_stem_wgrad(own.data_ptr(), opp.data_ptr(), self.acts[0].data_ptr(), self.gs[0].data_ptr(), n, Cc,
-                                      self.stem_partial.data_ptr(), st))
+            chk(L.bz_train_stem_wgrad(bd, self.acts[0].data_ptr(), self.gs[0].data_ptr(), n, Cc, self.stem_partial.data_ptr(), st))
             chk(L.bz_train_heads_wgrad(self.hv.data_ptr(), self.dl.data_ptr(), self.dv1.data_ptr(), n, self.VH, self.heads_w_partial.data_ptr(), st))
-            chk(L.bz_train_finish(ct.byref(self._partials), ct.byref(self._grads), Cc, Ly, self.VH, n, self.losses.data_ptr(), st))
+            chk(L.bz_train_finish(ct.byref(self._partials), ct.byref(self._grads), Cc, Ly, self.VH, n, self.losses.data_ptr(),
+                                  ct.byref(self._adam) if adam else None, st))
         return self.losses
+
+    def grads(self, own=None, opp=None, pi=None, z=None, idx=None):
+        """forward, losses, backward: every parameter's .grad is set; returns the static [loss, CE, MSE] tensor.
+        (own, opp, pi, z[, idx]) given: set_batch() first."""
+        if own is not None:
+            self.set_batch(own, opp, pi, z, idx)
+        return self.launch(adam=False)
+
+    def step(self):
+        """grads() and the Adam update: 10 launches (enable_adam() first)"""
+        return self.launch(adam=True)
 
 
 def rows_linear(x, W, b):

@@ -369,8 +369,7 @@ int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, int32_t n_la
 /* The two ends of the same step (csrc/bz_train_ends.hip), so that a whole   */
 /* step -- train.py:85-136's forward, loss, backward -- is 9 launches:       */
 /*   stem_fwd, pack_weights, tower_fwd, heads, tower_bwd, wgrad, stem_wgrad, */
-/*   heads_wgrad, finish                                                      */
-/* and only the optimiser update stays with the caller.  The net is           */
+/*   heads_wgrad, finish (+ the Adam update as a tenth launch).  The net is     */
 /* betazero_amd/net.py's (SURVEY 8(d) "net"): every pointer below is one of   */
 /* its parameter tensors (fp32, torch layout) or the gradient of one.         */
 /* n = batch, a multiple of 4 (and of bz_train_positions_per_workgroup(C)).   */
@@ -378,32 +377,55 @@ int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, int32_t n_la
 typedef struct bz_train_head_params {   /* pol: Conv2d(C, 2, 1); polfc: Linear(128, 65); val: Conv2d(C, 1, 1); v1: Linear(64, VH); v2: Linear(VH, 1) */
     const float *pol_w, *pol_b, *polfc_w, *polfc_b, *val_w, *val_b, *v1_w, *v1_b, *v2_w, *v2_b;
 } bz_train_head_params;
-typedef struct bz_train_grads {         /* where bz_train_finish writes d loss / d parameter, one tensor per parameter */
+typedef struct bz_train_tensors {       /* one fp32 device pointer per parameter tensor of the net: the gradients, the parameters, an Adam moment */
     float *stem_w, *stem_b, *tower_w, *tower_b, *pol_w, *pol_b, *polfc_w, *polfc_b, *val_w, *val_b, *v1_w, *v1_b, *v2_w, *v2_b;
-} bz_train_grads;
+} bz_train_tensors;
 typedef struct bz_train_partials {      /* the partial sums the kernels of one step leave behind */
     const float *tower, *tower_b;       /* bz_train_wgrad's partial / db_partial */
     const float *stem, *heads, *heads_w; /* bz_train_stem_wgrad's, bz_train_heads', bz_train_heads_wgrad's (bz_train_ends_sizes) */
     int32_t splits;                     /* bz_train_wgrad's splits */
 } bz_train_partials;
+/* The batch of a step.  This struct lives in DEVICE memory and is read by the kernels at launch time: a step captured
+ * into a HIP graph keeps working when the data set's tensors are replaced or another batch is drawn -- the host rewrites
+ * these 48 bytes (or just the idx array).  Batch position p is row idx[p] of the data set (clamped into [0, n_rows)), or
+ * row p when idx is NULL.  The rows are what bz_engine_pack_examples / the example block hold: (s, pi, z) of
+ * generate_training_games.py:12-23 in own/opp form. */
+typedef struct bz_train_batch {
+    const uint64_t *own, *opp;          /* [n_rows] bitboards, side-to-move canonical */
+    const float* pi;                    /* [n_rows][65] */
+    const int8_t* z;                    /* [n_rows] */
+    const int64_t* idx;                 /* [n] or NULL */
+    int64_t n_rows;
+} bz_train_batch;
+/* Adam behind bz_train_finish (torch.optim.Adam's arithmetic without weight decay / amsgrad: what train.py:87 constructs):
+ * one more launch that updates all 14 parameter tensors from the gradients just written.  hyper = 16 bytes of DEVICE memory
+ * {float learning rate; float steps done so far; float warm-up steps; float unused}: bz_train_finish advances the step
+ * count to t = steps done + 1 and the update runs at rate lr * min(1, t / warm-up) (warm-up 0: lr), so a captured graph can
+ * be replayed step after step with no host write in between; the caller writes the block to (re)start or change the rate. */
+typedef struct bz_train_adam {
+    float* hyper;
+    float beta1, beta2, eps;
+    bz_train_tensors p, m, v;           /* parameters (updated in place), first and second moments (zero before step 1) */
+} bz_train_adam;
 /* sizes[0..5] = number of partial vectors, floats per vector of: stem_wgrad, heads, heads_wgrad */
 int32_t bz_train_ends_sizes(int32_t C, int32_t n, int32_t* sizes);
 /* act0[pos][cell][c] (bf16) = relu(conv3x3(planes(own, opp)))[c][cell]: the bit planes never exist in memory */
-int32_t bz_train_stem_fwd(const uint64_t* own, const uint64_t* opp, int32_t n, const float* stem_w, const float* stem_b, int32_t C,
-                          void* act0, void* stream);
+int32_t bz_train_stem_fwd(const bz_train_batch* batch_dev, int32_t n, const float* stem_w, const float* stem_b, int32_t C, void* act0,
+                          void* stream);
 /* g0 = g[0] (d loss / d act[0], what bz_train_tower_bwd leaves there); partial [sizes[0]][sizes[1]] */
-int32_t bz_train_stem_wgrad(const uint64_t* own, const uint64_t* opp, const void* act0, const void* g0, int32_t n, int32_t C,
-                            float* partial, void* stream);
-/* heads + losses, forward and backward: act_top = act[L]; pi fp32 [n][65], z int8 [n]; loss = mean CE(pi, softmax(logits))
- * + mean (v - z)^2.  Writes g_top = g[L] (bf16 [n][64][C], the input of bz_train_tower_bwd), the per-position operands of
- * the FC weight gradients (hv fp32 [n][192], dl [n][65], dv1 [n][64]) and partial [sizes[2]][sizes[3]]. */
-int32_t bz_train_heads(const void* act_top, const float* pi, const int8_t* z, int32_t n, int32_t C, int32_t VH,
+int32_t bz_train_stem_wgrad(const bz_train_batch* batch_dev, const void* act0, const void* g0, int32_t n, int32_t C, float* partial,
+                            void* stream);
+/* heads + losses, forward and backward: act_top = act[L]; loss = mean CE(pi, softmax(logits)) + mean (v - z)^2 over the
+ * batch.  Writes g_top = g[L] (bf16 [n][64][C], the input of bz_train_tower_bwd), the per-position operands of the FC
+ * weight gradients (hv fp32 [n][192], dl [n][65], dv1 [n][64]) and partial [sizes[2]][sizes[3]]. */
+int32_t bz_train_heads(const void* act_top, const bz_train_batch* batch_dev, int32_t n, int32_t C, int32_t VH,
                        const bz_train_head_params* P, void* g_top, float* hv, float* dl, float* dv1, float* partial, void* stream);
 /* partial [sizes[4]][sizes[5]] */
 int32_t bz_train_heads_wgrad(const float* hv, const float* dl, const float* dv1, int32_t n, int32_t VH, float* partial, void* stream);
-/* every partial sum -> the gradient tensors (torch layouts); losses[3] = loss, policy CE, value MSE of the batch */
-int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_grads* G, int32_t C, int32_t n_layers, int32_t VH, int32_t n,
-                        float* losses, void* stream);
+/* every partial sum -> the gradient tensors G (torch layouts); losses[3] = loss, policy CE, value MSE of the batch;
+ * opt != NULL: followed by the Adam update of every parameter (a second launch) */
+int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_tensors* G, int32_t C, int32_t n_layers, int32_t VH, int32_t n,
+                        float* losses, const bz_train_adam* opt, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* In-library kernel timers: HIP events recorded on the launch stream around  */

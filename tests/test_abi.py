@@ -30,6 +30,20 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.EngineCfg) == 80
     assert C.sizeof(_lib.EngineLayout) == 21 * 8 + 8 + 3 * 8
+    # the training structs, against the header itself (compiled by gcc): pointer structs are easy to get out of step
+    import os
+    import subprocess
+    import tempfile
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        open(src, "w").write('#include <stdio.h>\n#include "bz_abi.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
+                             "sizeof(bz_train_head_params), sizeof(bz_train_tensors), sizeof(bz_train_partials), sizeof(bz_train_batch), "
+                             "sizeof(bz_train_adam), sizeof(bz_engine_cfg)); return 0; }\n")
+        subprocess.check_call(["gcc", "-I", inc, "-o", os.path.join(d, "s"), src])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [C.sizeof(t) for t in (_lib.TrainHeadParams, _lib.TrainTensors, _lib.TrainPartials, _lib.TrainBatch, _lib.TrainAdam,
+                                            _lib.EngineCfg)], sizes
 
 
 def test_argument_validation_without_gpu():

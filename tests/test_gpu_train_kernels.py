@@ -40,7 +40,8 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
 
 
-@pytest.mark.parametrize("C,L,n", [(64, 4, 16), (128, 2, 8), (128, 6, 12), (64, 8, 40)])
+# (at 64 channels batches below 1536 run 4 positions per workgroup, larger ones 8: both geometries are covered)
+@pytest.mark.parametrize("C,L,n", [(64, 4, 16), (128, 2, 8), (128, 6, 12), (64, 8, 40), (64, 2, 1536)])
 def test_tower_forward_and_saved_activations_vs_torch(C, L, n):
     """every layer's stored activation equals the torch reference (conv2d + bias + skip + relu, outputs rounded to
     bf16 like the kernel's) to 2 bf16 ulps of the tensor's range (measured ~4e-3 relative to max); the function's
@@ -67,7 +68,7 @@ def test_tower_forward_and_saved_activations_vs_torch(C, L, n):
     assert torch.equal(y, plan.acts[L].float().view(n, 8, 8, C).permute(0, 3, 1, 2))
 
 
-@pytest.mark.parametrize("C,L,n", [(64, 4, 16), (128, 4, 32), (64, 8, 64), (128, 12, 64)])
+@pytest.mark.parametrize("C,L,n", [(64, 4, 16), (128, 4, 32), (64, 8, 64), (128, 12, 64), (64, 4, 1536)])
 def test_tower_gradients_vs_torch_autograd_fp32(C, L, n):
     """d/dx0, d/dW, d/db of sum(y * gy) through the kernels against torch.autograd over the fp32 reference tower (its
     layer outputs rounded to bf16 with a straight-through gradient, as the kernels store them).  The kernels keep
@@ -215,7 +216,8 @@ def test_stem_kernel_and_its_weight_gradient_vs_torch(C, n):
     from betazero_amd import _lib
     m, plan, own, opp, pi, z = _net_case(C, 1, n, 21)
     L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
-    _lib.check(L.bz_train_stem_fwd(own.data_ptr(), opp.data_ptr(), n, m.stem.weight.data_ptr(), m.stem.bias.data_ptr(), C, plan.acts[0].data_ptr(), st))
+    plan.set_batch(own, opp, pi, z)
+    _lib.check(L.bz_train_stem_fwd(plan.batch_desc.data_ptr(), n, m.stem.weight.data_ptr(), m.stem.bias.data_ptr(), C, plan.acts[0].data_ptr(), st))
     x = _planes(own, opp)
     want = F.relu(F.conv2d(x, m.stem.weight, m.stem.bias, padding=1)).permute(0, 2, 3, 1).reshape(n, 64, C)
     got = plan.acts[0].float()
@@ -225,8 +227,8 @@ def test_stem_kernel_and_its_weight_gradient_vs_torch(C, n):
     # weight gradient
     g0 = torch.randn((n, 64, C), device=DEV).bfloat16()
     plan.gs[0].copy_(g0)
-    _lib.check(L.bz_train_stem_wgrad(own.data_ptr(), opp.data_ptr(), plan.acts[0].data_ptr(), plan.gs[0].data_ptr(), n, C, plan.stem_partial.data_ptr(), st))
-    _lib.check(L.bz_train_finish(_byref(plan._partials), _byref(plan._grads), C, plan.L, plan.VH, n, plan.losses.data_ptr(), st))
+    _lib.check(L.bz_train_stem_wgrad(plan.batch_desc.data_ptr(), plan.acts[0].data_ptr(), plan.gs[0].data_ptr(), n, C, plan.stem_partial.data_ptr(), st))
+    _lib.check(L.bz_train_finish(_byref(plan._partials), _byref(plan._grads), C, plan.L, plan.VH, n, plan.losses.data_ptr(), None, st))
     w, b = m.stem.weight.detach().clone().requires_grad_(True), m.stem.bias.detach().clone().requires_grad_(True)
     pre = F.conv2d(x, w, b, padding=1).permute(0, 2, 3, 1).reshape(n, 64, C)
     (pre * (g0.float() * (plan.acts[0] > 0))).sum().backward()
@@ -262,10 +264,11 @@ def test_heads_kernel_losses_and_gradients_vs_torch_fp32(C, n, VH):
     L, st, Ly = _lib.lib(), torch.cuda.current_stream().cuda_stream, plan.L
     x = torch.relu(torch.randn((n, 64, C), device=DEV) - 0.3).bfloat16()
     plan.acts[Ly].copy_(x)
-    _lib.check(L.bz_train_heads(plan.acts[Ly].data_ptr(), pi.data_ptr(), z.data_ptr(), n, C, VH, _byref(plan._head), plan.gs[Ly].data_ptr(),
+    plan.set_batch(own, opp, pi, z)
+    _lib.check(L.bz_train_heads(plan.acts[Ly].data_ptr(), plan.batch_desc.data_ptr(), n, C, VH, _byref(plan._head), plan.gs[Ly].data_ptr(),
                                 plan.hv.data_ptr(), plan.dl.data_ptr(), plan.dv1.data_ptr(), plan.heads_partial.data_ptr(), st))
     _lib.check(L.bz_train_heads_wgrad(plan.hv.data_ptr(), plan.dl.data_ptr(), plan.dv1.data_ptr(), n, VH, plan.heads_w_partial.data_ptr(), st))
-    _lib.check(L.bz_train_finish(_byref(plan._partials), _byref(plan._grads), C, Ly, VH, n, plan.losses.data_ptr(), st))
+    _lib.check(L.bz_train_finish(_byref(plan._partials), _byref(plan._grads), C, Ly, VH, n, plan.losses.data_ptr(), None, st))
     got = {k: getattr(m, k).weight.grad.clone() for k in ("pol", "polfc", "val", "v1", "v2")}
     gotb = {k: getattr(m, k).bias.grad.clone() for k in ("pol", "polfc", "val", "v1", "v2")}
     losses, g_top = plan.losses.clone(), plan.gs[Ly].float().clone()
@@ -314,3 +317,64 @@ def test_whole_step_on_the_kernels_vs_torch_autograd_fp32(C, NB, n):
     assert all(0.9 < r < 1.1 for k, r in mag.items() if got[k].numel() >= 64), mag
     with pytest.raises(AssertionError):
         plan.grads(own, opp, pi, z)      # ... and StepPlan notices that its gradient tensors were swapped out
+
+
+def test_step_gathers_its_batch_rows_itself_and_clamps_bad_indices():
+    """the kernels read the batch through the device descriptor: rows idx of a larger data set give bit for bit the
+    losses and gradients of the same rows handed over contiguously; an index outside the data set is clamped to its
+    last / first row instead of faulting; pointing the plan at another data set changes nothing but the 48 bytes."""
+    n, rows = 32, 304
+    m, plan, own, opp, pi, z = _net_case(64, 1, rows, 24)
+    from betazero_amd.train_kernels import StepPlan
+    plan = StepPlan(m, n)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    idx = torch.randint(0, rows, (n,), device=DEV, generator=gen)
+    a = plan.grads(own, opp, pi, z, idx).clone()
+    ga = {k: p.grad.clone() for k, p in m.named_parameters()}
+    b = plan.grads(own[idx].contiguous(), opp[idx].contiguous(), pi[idx].contiguous(), z[idx].contiguous()).clone()
+    assert torch.equal(a, b) and all(torch.equal(ga[k], p.grad) for k, p in m.named_parameters())
+    bad = idx.clone()
+    bad[3], bad[7] = rows + 1000, -5
+    good = idx.clone()
+    good[3], good[7] = rows - 1, 0
+    c = plan.grads(own, opp, pi, z, bad).clone()
+    d = plan.grads(own, opp, pi, z, good).clone()
+    assert torch.equal(c, d) and not torch.equal(c, a)
+    with pytest.raises(ValueError):
+        plan.set_batch(own, opp, pi, z, idx[:8])              # not a whole batch of indices
+    with pytest.raises(ValueError):
+        plan.set_batch(own[:8], opp[:8], pi[:8], z[:8])       # fewer rows than the batch, no index
+
+
+@pytest.mark.parametrize("warmup", [0, 4])
+def test_adam_kernel_equals_torch_adam(warmup):
+    """6 steps with the update applied by k_train_adam behind k_train_finish (step count and learning-rate warm-up kept on the device)
+    against torch.optim.Adam fed the SAME gradients (the ones the kernel also leaves in .grad; its rate set by hand to
+    lr * min(1, t / warmup)): every parameter equal to 1e-5 of an lr-sized step plus a few fp32 ulps after each step (fp32
+    arithmetic in a different order), the device counter at 6.  (Letting the second model compute its own gradients would test chaos, not
+    Adam: a 1e-9 difference in a weight flips bf16 roundings in the tower and moves single updates by percents of lr.)"""
+    import copy
+    n = 64
+    m1, plan1, own, opp, pi, z = _net_case(64, 2, n, 25)
+    m0 = copy.deepcopy(m1)
+    m2 = copy.deepcopy(m1)
+    for p in m2.parameters():
+        p.grad = None
+    lr = 3e-3
+    plan1.enable_adam(lr, warmup_steps=warmup)
+    opt = torch.optim.Adam(m2.parameters(), lr=lr)
+    plan1.set_batch(own, opp, pi, z)
+    for t in range(1, 7):
+        plan1.step()
+        for g in opt.param_groups:
+            g["lr"] = lr * min(1.0, t / warmup) if warmup else lr
+        for a, b in zip(m1.parameters(), m2.parameters()):
+            b.grad = a.grad.clone()
+        opt.step()
+        for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert float((a - b).abs().max()) <= 1e-5 * lr * t + 5e-7 * float(b.abs().max()), (t, k, float((a - b).abs().max()))   # a few fp32 ulps of the weight
+    assert plan1.adam_t == 6
+    moved = max(float((a - b).abs().max()) for a, b in zip(m1.parameters(), m0.parameters()))
+    assert moved > 1e-3          # ... and the parameters did move
+    plan1.reset_adam(steps_done=0)
+    assert plan1.adam_t == 0 and all(float(v.abs().max()) == 0.0 for v in plan1.adam_v.values())

@@ -90,6 +90,7 @@ def test_training_kernels_do_not_spill(tmp_path):
     scratch memory: 272 bytes per lane) and really reads both operands through the LDS transpose read"""
     res = _resources("bz_train.hip", tmp_path)
     for parts in (("k_train_fwd", "Li64ELi8E"), ("k_train_fwd", "Li128ELi4E"), ("k_train_bwd", "Li64ELi8E"), ("k_train_bwd", "Li128ELi4E"),
+                  ("k_train_fwd", "Li64ELi4E"), ("k_train_bwd", "Li64ELi4E"),
                   ("k_train_wgrad", "Li64E"), ("k_train_wgrad", "Li128E")):
         k = _find(res, *parts)
         assert k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
@@ -103,7 +104,7 @@ def test_training_end_kernels_do_not_spill(tmp_path):
     of registers although only its LDS (130 KB) decides the occupancy"""
     res = _resources("bz_train_ends.hip", tmp_path)
     for parts in (("k_train_stemILi64E",), ("k_train_stemILi128E",), ("k_train_stem_wgradILi64E",), ("k_train_stem_wgradILi128E",),
-                  ("k_train_headsILi64E",), ("k_train_headsILi128E",), ("k_train_heads_wgrad",), ("k_train_finish",)):
+                  ("k_train_headsILi64E",), ("k_train_headsILi128E",), ("k_train_heads_wgrad",), ("k_train_finish",), ("k_train_adam",)):
         k = _find(res, *parts)
         assert k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
     assert _find(res, "k_train_headsILi128E")["vgpr"] <= 128

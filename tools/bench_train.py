@@ -29,7 +29,7 @@ ex = DeviceExamples.from_host(Examples(x & ~y, y & ~x, pi, rng.integers(-1, 2, n
                                        np.zeros(n, np.uint8), np.arange(n), np.zeros(n, np.int32), 8))
 
 
-def run(label, autocast, graph, bench, cl, kernels=False, step_kernels=None):
+def run(label, autocast, graph, bench, cl, kernels=False, step_kernels=None, fused_adam=None):
     torch.backends.cudnn.benchmark = bench
     torch.manual_seed(0)
     m = PolicyValueNet(C, NB, 64, fused_tower=kernels).cuda()
@@ -37,7 +37,7 @@ def run(label, autocast, graph, bench, cl, kernels=False, step_kernels=None):
         m = m.to(memory_format=torch.channels_last)
     idx = [torch.randint(0, n, (B,), device="cuda:0") for _ in range(8)]
     if graph:
-        g = GraphedTrainStep(m, lr=1e-3, batch=B, autocast=autocast, tower_kernels=kernels, step_kernels=step_kernels)
+        g = GraphedTrainStep(m, lr=1e-3, batch=B, autocast=autocast, tower_kernels=kernels, step_kernels=step_kernels, fused_adam=fused_adam)
         step = lambda i: g(ex, idx[i % 8])  # noqa: E731
     else:
         opt = make_optimizer(m, lr=1e-3)
@@ -96,15 +96,18 @@ def ends_only():
     m = PolicyValueNet(C, NB, 64, fused_tower=True).cuda()
     p = StepPlan(m, B)
     Ly, st = p.L, torch.cuda.current_stream().cuda_stream
-    own, opp, pit, z = ex.own[:B].contiguous(), ex.opp[:B].contiguous(), ex.pi[:B].contiguous(), ex.z[:B].contiguous()
-    p.grads(own, opp, pit, z)
+    idx = torch.randint(0, n, (B,), device="cuda:0")
+    p.enable_adam(0.0)
+    p.grads(ex.own, ex.opp, ex.pi, ex.z, idx)
+    bd = p.batch_desc.data_ptr()
     calls = {
-        "k_train_stem": lambda: L.bz_train_stem_fwd(own.data_ptr(), opp.data_ptr(), B, m.stem.weight.data_ptr(), m.stem.bias.data_ptr(), C, p.acts[0].data_ptr(), st),
-        "k_train_heads": lambda: L.bz_train_heads(p.acts[Ly].data_ptr(), pit.data_ptr(), z.data_ptr(), B, C, 64, ctypes.byref(p._head), p.gs[Ly].data_ptr(),
+        "k_train_stem": lambda: L.bz_train_stem_fwd(bd, B, m.stem.weight.data_ptr(), m.stem.bias.data_ptr(), C, p.acts[0].data_ptr(), st),
+        "k_train_heads": lambda: L.bz_train_heads(p.acts[Ly].data_ptr(), bd, B, C, 64, ctypes.byref(p._head), p.gs[Ly].data_ptr(),
                                                   p.hv.data_ptr(), p.dl.data_ptr(), p.dv1.data_ptr(), p.heads_partial.data_ptr(), st),
-        "k_train_stem_wgrad": lambda: L.bz_train_stem_wgrad(own.data_ptr(), opp.data_ptr(), p.acts[0].data_ptr(), p.gs[0].data_ptr(), B, C, p.stem_partial.data_ptr(), st),
+        "k_train_stem_wgrad": lambda: L.bz_train_stem_wgrad(bd, p.acts[0].data_ptr(), p.gs[0].data_ptr(), B, C, p.stem_partial.data_ptr(), st),
         "k_train_heads_wgrad": lambda: L.bz_train_heads_wgrad(p.hv.data_ptr(), p.dl.data_ptr(), p.dv1.data_ptr(), B, 64, p.heads_w_partial.data_ptr(), st),
-        "k_train_finish": lambda: L.bz_train_finish(ctypes.byref(p._partials), ctypes.byref(p._grads), C, Ly, 64, B, p.losses.data_ptr(), st)}
+        "k_train_finish": lambda: L.bz_train_finish(ctypes.byref(p._partials), ctypes.byref(p._grads), C, Ly, 64, B, p.losses.data_ptr(), None, st),
+        "k_train_finish + k_train_adam": lambda: L.bz_train_finish(ctypes.byref(p._partials), ctypes.byref(p._grads), C, Ly, 64, B, p.losses.data_ptr(), ctypes.byref(p._adam), st)}
     print("the ends of the step alone (csrc/bz_train_ends.hip):")
     for name, fn in calls.items():
         for _ in range(5):
@@ -122,7 +125,8 @@ print(f"net {C} channels x {NB} blocks, batch {B}")
 print("tower kernels alone (csrc/bz_train.hip):")
 tower_only()
 ends_only()
-run("bf16 graph  whole step on HIP kernels (9 launches + Adam)", True, True, False, False, kernels=True, step_kernels=True)
+run("bf16 graph  whole step on HIP kernels incl. Adam (10 launches)", True, True, False, False, kernels=True, step_kernels=True)
+run("bf16 graph  whole step on HIP kernels + torch's fused Adam", True, True, False, False, kernels=True, step_kernels=True, fused_adam=False)
 run("bf16 graph  HIP tower kernels inside torch autograd", True, True, False, False, kernels=True, step_kernels=False)
 run("bf16 autocast graph  miopen-default    nchw", True, True, False, False)
 if not QUICK:
