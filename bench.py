@@ -418,6 +418,58 @@ def run_net(ctx, B, K, W, fp8):
                          "avg_launch_ms": avg_ms, "flop_per_launch": B * NET_FLOP_PER_POS}}
 
 
+def run_train(ctx, batch, K, W):
+    """SURVEY 8(f) row 4 inside the driver-timed process: K optimisation steps of the benchmark net (6 blocks x 128
+    channels) on a synthetic data set, the whole step -- stem, tower, heads, losses, every gradient, Adam -- as 10
+    hand-written kernels replayed as one HIP graph (betazero_amd.train.GraphedTrainStep).  The figure of merit is the
+    convolution work (forward + backward-data + backward-weights of the 12 conv3x3 layers and the stem) per second
+    against the dense bf16 MFMA peak."""
+    import numpy as np
+    import torch
+    from betazero_amd.engine import DeviceExamples, Examples
+    from betazero_amd.net import PolicyValueNet
+    from betazero_amd.train import GraphedTrainStep
+    C, NB = 128, 6
+    rng = np.random.default_rng(0)
+    n = 8 * batch
+    x = rng.integers(0, 2**63, size=n, dtype=np.int64).astype(np.uint64)
+    y = rng.integers(0, 2**63, size=n, dtype=np.int64).astype(np.uint64)
+    pi = rng.random((n, 65)).astype(np.float32)
+    pi /= pi.sum(1, keepdims=True)
+    ex = DeviceExamples.from_host(Examples(x & ~y, y & ~x, pi, rng.integers(-1, 2, n).astype(np.int8), np.ones(n, np.int8),
+                                           np.zeros(n, np.uint8), np.arange(n), np.zeros(n, np.int32), 8), ctx.dev)
+    torch.manual_seed(0)
+    step = GraphedTrainStep(PolicyValueNet(C, NB, 64, fused_tower=True).to(ctx.dev), lr=1e-3, batch=batch, device=ctx.dev)
+    assert step.step_plan is not None and step.fused_adam   # the kernels, not autograd
+    idx = [torch.randint(0, n, (batch,), device=ctx.dev) for _ in range(8)]
+    first = None
+    for i in range(W):
+        out = step(ex, idx[i % 8])
+        first = out if first is None else first
+    ctx.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(K):
+        out = step(ex, idx[i % 8])
+    e1.record()
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / K
+    losses = [float(v) for v in out]
+    assert all(np.isfinite(losses)) and losses[0] < float(first[0]), (losses, first)   # it is learning its 8 batches, not idling
+    flop = 3 * (2 * 64 * 9 * C * C * 2 * NB + 2 * 64 * 9 * 2 * C) * batch
+    ach = flop / (dev_ms * 1e-3) / 1e12
+    return {"metric": "train_steps_per_s", "value": K / dt, "unit": "steps/s", "n_gpus": ctx.world, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"train_step_convnet6x128_batch{batch}_bf16", "optimizer": "Adam (as its own kernel)",
+                       "launches_per_step": 10, "loss_first_last": [float(first[0]), losses[0]]},
+            "roofline": {"bound": "mfma", "kernel": "k_train_fwd + k_train_bwd + k_train_wgrad (+ the six end kernels)",
+                         "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": dev_ms, "flop_per_launch": flop,
+                         "note": "whole step (10 kernels) timed with events on the launch stream; flop = convolution work only"}}
+
+
 def run_env(ctx, n, K, W):
     """the batched board-env step on its own (bz_reversi_step_batch: legal-move mask, apply-move / flip, terminal /
     winner for n games per launch; 42 algorithmic bytes per step): every game plays the lowest legal
@@ -730,7 +782,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt", "net", "env"],
+    ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt", "net", "env", "train"],
                     help="reversi = BASELINE cfg 3 (default, the metric), ttt = cfg 2, net = cfg 5 (net forward only), "
                          "env = the batched board-env step kernel alone")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
@@ -810,6 +862,9 @@ def main():
     if args.workload == "net":  # BASELINE cfg 5: leaf-eval batch 8192, fp8 e4m3 net, MFMA-utilisation run
         out = run_net(ctx, args.games or 8192, args.steps if args.steps is not None else 1000,
                       args.warmup if args.warmup is not None else 50, (args.precision or "fp8") == "fp8")
+    elif args.workload == "train":
+        out = run_train(ctx, args.games or 1024, args.steps if args.steps is not None else 200,
+                        args.warmup if args.warmup is not None else 20)
     elif args.workload == "env":
         out = run_env(ctx, args.games or (1 << 26), args.steps if args.steps is not None else 20,
                       args.warmup if args.warmup is not None else 3)
@@ -842,7 +897,9 @@ def main():
                         ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0)),
                         ("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
                         ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
-                        ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3))):
+                        ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3)),
+                        # the training step of the benchmark net, all on hand-written kernels
+                        ("train_step", lambda: run_train(ctx, 1024, 200, 20))):
                     try:
                         note(f"secondary {name}")
                         r = fn()
