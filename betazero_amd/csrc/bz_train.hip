@@ -247,12 +247,24 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 template <int C_> struct Wg {
     static constexpr int C = C_, MT = C / 32, CELL = 2 * C, ZC = CELL / 16;
     static constexpr int NH = C / 64;                       // workgroups that share a (layer, slice): one per 64 output channels
-    static constexpr int NTW = MT / 2;                      // N tiles (32 output channels) per wave: 1 (C = 64), 2 (C = 128)
+    static constexpr int NTW = 2;                           // N tiles (32 output channels) per wave: both of the workgroup's 64 channels
     static constexpr int GCELL = 128, GZC = 8;              // the workgroup's 64 output channels of a gradient cell
     static constexpr int P2 = 256 / C;                      // positions per stage
+    // waves per workgroup.  The workgroup's 9 x MT x 2 accumulator tiles are dealt as (M tile) x (tap group), every wave
+    // taking both N tiles (an activation fragment then feeds two MFMAs: 14 transpose reads per 10 MFMAs):
+    //   C =  64: 4 waves = 2 M tiles x (taps 0-4 | taps 5-8)   -> 10 / 8 tiles per wave
+    //   C = 128: 8 waves = 4 M tiles x (taps 0-4 | taps 5-8)   -> 10 / 8 tiles per wave, two waves per SIMD
+    // (Round 4's first split -- C = 128: 4 waves x all 9 taps x 2 N tiles -- meant 288 accumulator registers per wave,
+    // more than the 256 AGPRs: the compiler rotated three tiles through the VGPR file with 96 v_accvgpr moves per 18 MFMAs,
+    // and the VALU issue slots those take are the MFMAs' own: 338 us where the matrix work is 110.  C = 64: 4 waves x 9 taps x
+    // ONE N tile read 20 fragments per 9 MFMAs: LDS-bound.)
+    static constexpr int NW = 2 * MT, NT = 64 * NW;
+    static constexpr int NTG = 2 / NTW;                     // N tile groups (1)
+    static constexpr int TGN = NW / (MT * NTG);             // tap groups (2)
     static constexpr int ACELLS = 91, A_TILE = ACELLS * CELL, G_TILE = 64 * GCELL;
     static constexpr int STAGE = P2 * (A_TILE + G_TILE);
-    static constexpr int NLA = P2 * 64 * ZC / 256, NLG = P2 * 64 * GZC / 256;  // 16-byte loads per thread and stage
+    static constexpr int NLA = P2 * 64 * ZC / NT, NLG = P2 * 64 * GZC / NT;  // 16-byte loads per thread and stage
+    static_assert(NLA * NT == P2 * 64 * ZC && NLG * NT == P2 * 64 * GZC && TGN * MT * NTG == NW, "the stage must split evenly over the threads");
     static constexpr int LDS = 2 * STAGE;
     static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
     static __device__ __forceinline__ int a_swz(int idx) { return C == 128 ? (idx & 3) : ((idx >> 1) & 1); }
@@ -283,10 +295,10 @@ template <class G>
 __device__ __forceinline__ void wg_fetch(u32x4 (&ra)[G::NLA], u32x4 (&rg)[G::NLG], const u32x4* A, const u32x4* Gr, int s, int half, int tid) {
     const size_t base = (size_t)s * G::P2 * 64 * G::ZC;
 #pragma unroll
-    for (int j = 0; j < G::NLA; ++j) ra[j] = A[base + tid + 256 * j];
+    for (int j = 0; j < G::NLA; ++j) ra[j] = A[base + tid + G::NT * j];
 #pragma unroll
     for (int j = 0; j < G::NLG; ++j) {  // chunk k (0..7) of the workgroup's half of cell (p, c)
-        const int i = tid + 256 * j, k = i % G::GZC, pc = i / G::GZC;
+        const int i = tid + G::NT * j, k = i % G::GZC, pc = i / G::GZC;
         rg[j] = Gr[base + (size_t)pc * G::ZC + half * G::GZC + k];
     }
 }
@@ -294,50 +306,35 @@ template <class G>
 __device__ __forceinline__ void wg_stash(const u32x4 (&ra)[G::NLA], const u32x4 (&rg)[G::NLG], char* st, int tid) {
 #pragma unroll
     for (int j = 0; j < G::NLA; ++j) {
-        const int i = tid + 256 * j, k = i % G::ZC, c = (i / G::ZC) % 64, p = i / (G::ZC * 64);
+        const int i = tid + G::NT * j, k = i % G::ZC, c = (i / G::ZC) % 64, p = i / (G::ZC * 64);
         const int ai = 9 * ((c >> 3) + 1) + (c & 7) + 1;
         *reinterpret_cast<u32x4*>(st + G::a_off(p, ai, k >> 2) + ((k & 3) << 4)) = ra[j];
     }
 #pragma unroll
     for (int j = 0; j < G::NLG; ++j) {
-        const int i = tid + 256 * j, k = i % G::GZC, c = (i / G::GZC) % 64, p = i / (G::GZC * 64);
+        const int i = tid + G::NT * j, k = i % G::GZC, c = (i / G::GZC) % 64, p = i / (G::GZC * 64);
         *reinterpret_cast<u32x4*>(st + G::g_off(p, c, k >> 2) + ((k & 3) << 4)) = rg[j];
     }
 }
 
-template <int C>
-__global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
+// the stages of one workgroup for the taps [T0, T1) of one wave (all waves run the same number of stages and barriers)
+template <int C, int T0, int T1>
+__device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int tid, int lane, int mt, int nt0, int l, int split, int half,
+                                           int s_begin, int s_end, bool do_bias) {
     typedef Wg<C> G;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // the NH workgroups of one (layer, batch slice) sit 8 workgroups apart: same XCD (workgroups go round-robin over the 8
-    // XCDs), launched together -> the activations they both read meet in that XCD's L2
-    const int b = blockIdx.x, item = (b / (8 * G::NH)) * 8 + (b & 7), half = (b >> 3) % G::NH;
-    if (item >= T.L * T.S) return;
-    const int l = item / T.S, split = item % T.S;
-    // this slice's stages (P2 positions each)
-    const int stages_all = T.n / G::P2;
-    const int s_begin = (int)((long long)stages_all * split / T.S), s_end = (int)((long long)stages_all * (split + 1) / T.S);
-    const int mt = w % G::MT, nt0 = (w / G::MT) * G::NTW;   // C = 64: (mt, nt) = (w & 1, w >> 1); C = 128: mt = w, both N tiles
-    // zero both stages' activation images once: the loads below only ever write board cells
-    for (int i = tid; i < 2 * G::P2 * G::A_TILE / 16; i += 256) {
-        const int st = i / (G::P2 * G::A_TILE / 16), o = i % (G::P2 * G::A_TILE / 16);
-        *reinterpret_cast<uint4*>(smem + st * G::STAGE + o * 16) = make_uint4(0, 0, 0, 0);
-    }
+    constexpr int NTAP = T1 - T0;
     const size_t slot = (size_t)T.n * 64 * G::ZC;  // uint4 per tensor
     const u32x4* A = reinterpret_cast<const u32x4*>(T.acts) + (size_t)l * slot;
     const u32x4* Gr = reinterpret_cast<const u32x4*>(T.gs) + (size_t)l * slot;
     u32x4 ra[G::NLA], rg[G::NLG];
-    f32x16 acc[9][G::NTW];
+    f32x16 acc[NTAP][G::NTW];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int nt = 0; nt < G::NTW; ++nt) acc[t][nt] = (f32x16)(0.0f);
-    // the bias gradient rides along in the waves that hold M-tile 0: a lane's gradient fragment is 8 cells of ONE output
-    // channel, so their sum is the lane's share of that channel's column sum (one float per N tile; the two k halves of a
-    // channel leave as two partial sums)
-    const bool do_bias = mt == 0;  // wave-uniform
+    // the bias gradient rides along in the waves that hold M-tile 0 (and tap group 0): a lane's gradient fragment is 8 cells
+    // of ONE output channel, so their sum is the lane's share of that channel's column sum (one float per N tile; the two k
+    // halves of a channel leave as two partial sums)
     float bsum[G::NTW];
 #pragma unroll
     for (int nt = 0; nt < G::NTW; ++nt) bsum[nt] = 0.0f;
@@ -345,7 +342,6 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
     // channels), lane 4q + pp of the group supplies cell q of the block, channels 4pp .. 4pp + 3
     const int g = lane >> 4, hh = g >> 1, cg = g & 1, q = (lane >> 2) & 3, pp = lane & 3;
     const int inner = 32 * cg + 8 * pp;
-    if (s_begin >= s_end) return;  // (block-uniform; cannot happen: splits <= stages)
     wg_fetch<G>(ra, rg, A, Gr, s_begin, half, tid);
     __syncthreads();  // the zero fill is complete
     wg_stash<G>(ra, rg, smem, tid);
@@ -372,11 +368,11 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
                         for (int j = 0; j < 8; ++j) bsum[nt] += (float)bf[nt][j];
                 }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {  // tap t = 3 (dy + 1) + (dx + 1): the activations one row / one column over
+                for (int t = T0; t < T1; ++t) {  // tap t = 3 (dy + 1) + (dx + 1): the activations one row / one column over
                     const int i0 = 9 * (y + t / 3) + (q + t % 3 - 1) + 1, i1 = i0 + 4;
                     const bf16x8 af = tr_pair(st, G::a_off(p, i0, mt) + inner, G::a_off(p, i1, mt) + inner);
 #pragma unroll
-                    for (int nt = 0; nt < G::NTW; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t][nt], 0, 0, 0);
+                    for (int nt = 0; nt < G::NTW; ++nt) acc[t - T0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t - T0][nt], 0, 0, 0);
                 }
             }
         }
@@ -387,17 +383,47 @@ __global__ void __launch_bounds__(256, 1) k_train_wgrad(WgradArgs T) {
     const int r = lane & 31, h = lane >> 5;
     float* P = T.partial + (((size_t)l * T.S + split) * 9) * C * C;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int nt = 0; nt < G::NTW; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int ci = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h, co = 64 * half + 32 * (nt0 + nt) + r;
-                P[((size_t)t * C + ci) * C + co] = acc[t][nt][i];
+                P[((size_t)t * C + ci) * C + co] = acc[t - T0][nt][i];
             }
     if (do_bias) {  // lane (r, h): channel r of the tile, k half h -> partial sums [L][2 S][co]
 #pragma unroll
         for (int nt = 0; nt < G::NTW; ++nt) T.db_partial[((size_t)l * 2 * T.S + 2 * split + h) * C + 64 * half + 32 * (nt0 + nt) + r] = bsum[nt];
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(Wg<C>::NT, 1) k_train_wgrad(WgradArgs T) {
+    typedef Wg<C> G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the NH workgroups of one (layer, batch slice) sit 8 workgroups apart: same XCD (workgroups go round-robin over the 8
+    // XCDs), launched together -> the activations they both read meet in that XCD's L2
+    const int b = blockIdx.x, item = (b / (8 * G::NH)) * 8 + (b & 7), half = (b >> 3) % G::NH;
+    if (item >= T.L * T.S) return;
+    const int l = item / T.S, split = item % T.S;
+    // this slice's stages (P2 positions each)
+    const int stages_all = T.n / G::P2;
+    const int s_begin = (int)((long long)stages_all * split / T.S), s_end = (int)((long long)stages_all * (split + 1) / T.S);
+    const int mt = w % G::MT, rest = w / G::MT, nt0 = (rest % G::NTG) * G::NTW, tg = rest / G::NTG;
+    // zero both stages' activation images once: the loads below only ever write board cells
+    for (int i = tid; i < 2 * G::P2 * G::A_TILE / 16; i += G::NT) {
+        const int st = i / (G::P2 * G::A_TILE / 16), o = i % (G::P2 * G::A_TILE / 16);
+        *reinterpret_cast<uint4*>(smem + st * G::STAGE + o * 16) = make_uint4(0, 0, 0, 0);
+    }
+    if (s_begin >= s_end) return;  // (block-uniform; cannot happen: splits <= stages)
+    const bool do_bias = mt == 0 && tg == 0;  // wave-uniform
+    if constexpr (G::TGN == 1) {
+        wgrad_wave<C, 0, 9>(T, smem, tid, lane, mt, nt0, l, split, half, s_begin, s_end, do_bias);
+    } else {
+        if (tg == 0) wgrad_wave<C, 0, 5>(T, smem, tid, lane, mt, nt0, l, split, half, s_begin, s_end, do_bias);
+        else wgrad_wave<C, 5, 9>(T, smem, tid, lane, mt, nt0, l, split, half, s_begin, s_end, do_bias);
     }
 }
 
@@ -484,11 +510,11 @@ BZ_EXPORT int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, in
     if (C == 64) {
         static bool once = false;
         if (!once) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_wgrad<64>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg<64>::LDS); if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_wgrad)"); once = true; }
-        hipLaunchKernelGGL(k_train_wgrad<64>, dim3(grid), dim3(256), Wg<64>::LDS, s, T);
+        hipLaunchKernelGGL(k_train_wgrad<64>, dim3(grid), dim3(Wg<64>::NT), Wg<64>::LDS, s, T);
     } else {
         static bool once = false;
         if (!once) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_wgrad<128>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg<128>::LDS); if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_wgrad)"); once = true; }
-        hipLaunchKernelGGL(k_train_wgrad<128>, dim3(grid), dim3(256), Wg<128>::LDS, s, T);
+        hipLaunchKernelGGL(k_train_wgrad<128>, dim3(grid), dim3(Wg<128>::NT), Wg<128>::LDS, s, T);
     }
     BZ_LAUNCH_CHECK("k_train_wgrad");
     return BZ_OK;
