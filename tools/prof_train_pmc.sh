@@ -12,3 +12,5 @@ run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
 run inst SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES &&
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE
+# the databases are too big to travel back (64 MiB limit on gpurun_out/): summarise here, keep only the CSVs
+cd "$GRAFT_REPO_ROOT" && python3 tools/summarize_prof.py r04 --src "$OUT" --out "$OUT/summary" && rm -rf "$OUT"/train${C}_*/
