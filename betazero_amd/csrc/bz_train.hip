@@ -48,8 +48,17 @@ __device__ __forceinline__ void load_tile(char* buf, const __bf16* src, int pos0
         *reinterpret_cast<uint4*>(buf + p * G::TILE + G::cell_off(p, c, k)) = s[i];
     }
 }
+#if defined(BZ_EXP_COPY_AFTER_BARRIER) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_COPY_AFTER_BARRIER is a diagnostic variant (the round-4 placement of the copy-out, for A/B): build it through betazero_amd.build.build_variant()"
+#endif
+#if defined(BZ_EXP_NO_TRAIN_STORES) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_NO_TRAIN_STORES is a diagnostic variant (timing only: the kernels then store nothing): build it through betazero_amd.build.build_variant()"
+#endif
 template <class G>
 __device__ __forceinline__ void store_tile(const char* buf, __bf16* dst, int pos0, int tid) {
+#ifdef BZ_EXP_NO_TRAIN_STORES
+    return;
+#endif
     constexpr int ZC = G::CELL / 16, N = G::P * 64 * ZC;
     uint4* d = reinterpret_cast<uint4*>(dst) + (size_t)pos0 * 64 * ZC;
 #pragma unroll 4
@@ -105,11 +114,29 @@ __device__ __forceinline__ void epilogue_train(f32x16 (&acc)[G::MW][G::NU], char
         if (!BWD) bits[q] = word;
     }
 }
+// The copy-out of a layer's result (LDS tile -> HBM, what the weight gradients read) rides in the NEXT layer's epilogue on the
+// row-tile shapes: the tile is that layer's input, complete since the barrier and never written by its epilogue.  Issued
+// right behind a layer's own barrier the 16 stores per lane sit in front of the next K-loop's weight loads (vmcnt retires in
+// order); in the epilogue they have ~1.5 us without a vector-memory wait to land.  Same-box A/B (tools/exp_train_stores.sh,
+// profiles/r04_exp_train_stores.txt): -1.5 % (128 channels) .. -3.4 / -6.5 % (64 channels x 8 positions, forward / backward);
+// the half-tile shape measured +3 % on backward and keeps the copy behind the barrier.  The copy-out itself costs 10-20 % of
+// these kernels wherever it is issued (the same A/B against a build that stores nothing): 64 KB per workgroup and layer
+// through the CU's 64-B/clk path to L2, in step across all workgroups.
+template <class G> constexpr bool kCopyInEpilogue =
+#ifdef BZ_EXP_COPY_AFTER_BARRIER
+    false;
+#else
+    G::ROWT;
+#endif
 template <class G, bool BWD> struct EpTrain {
     unsigned* bits;   // the lane's 128 ReLU bits of this layer (FWD: written, BWD: read)
     bool use_bits;
+    const char* copy_buf;   // the workgroup's LDS tile to copy out first (this layer's input) ...
+    __bf16* copy_dst;       // ... to here (the workgroup's first position of the destination tensor), or null: nothing to copy
+    int tid;
     __device__ __forceinline__ void operator()(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt0,
                                                int r, int h) const {
+        if (kCopyInEpilogue<G> && copy_dst) store_tile<G>(copy_buf, copy_dst, 0, tid);
         unsigned (&b)[4] = *reinterpret_cast<unsigned (*)[4]>(bits);
         epilogue_train<G, BWD>(acc, out, second, bias, wt0, r, h, b, use_bits);
     }
@@ -153,19 +180,25 @@ __global__ void __launch_bounds__(256, 1) k_train_fwd(TrainArgs T) {
     load_tile<G>(bufX, T.in, pos0, tid);
     __syncthreads();
     const size_t slot = (size_t)T.n * 64 * G::C;                       // elements of one activation tensor
+    __bf16* const mine = T.out + (size_t)pos0 * 64 * G::C;             // the workgroup's positions in the first output tensor
     const size_t mslot = (size_t)(T.n / G::P) * 256;                    // mask words of one layer
     uint4* mk = T.masks + (size_t)blockIdx.x * 256 + tid;
 #pragma unroll 1
     for (int blk = 0; blk < T.n_layers / 2; ++blk) {
         unsigned bits[4];
-        conv_layer<0, G>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * G::C, WS, ap, w, r, h, tacc, EpTrain<G, false>{bits, true});
+        // (act[2 blk] = X, the previous block's result, leaves in this layer's epilogue; act[0] came from HBM)
+        conv_layer<0, G>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * G::C, WS, ap, w, r, h, tacc,
+                         EpTrain<G, false>{bits, true, bufX, blk > 0 ? mine + (size_t)(2 * blk - 1) * slot : nullptr, tid});
+        if constexpr (!kCopyInEpilogue<G>)
+            if (__bf16* cd = blk > 0 ? mine + (size_t)(2 * blk - 1) * slot : nullptr) store_tile<G>(bufX, cd, 0, tid);
         mk[(size_t)(2 * blk) * mslot] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
-        store_tile<G>(bufM, T.out + (size_t)(2 * blk) * slot, pos0, tid);
         conv_layer<G::NCH % G::DEPTH, G>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * G::C, WS, ap, w, r, h, tacc,
-                                         EpTrain<G, false>{bits, true});
+                                         EpTrain<G, false>{bits, true, bufM, mine + (size_t)(2 * blk) * slot, tid});
+        if constexpr (!kCopyInEpilogue<G>)
+            if (__bf16* cd = mine + (size_t)(2 * blk) * slot) store_tile<G>(bufM, cd, 0, tid);
         mk[(size_t)(2 * blk + 1) * mslot] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
-        store_tile<G>(bufX, T.out + (size_t)(2 * blk + 1) * slot, pos0, tid);
     }
+    store_tile<G>(bufX, mine + (size_t)(T.n_layers - 1) * slot, 0, tid);
 }
 
 // backward-data: g[L] (HBM) -> g[L-1 .. 0] (HBM).  g[l] = d(loss)/d(pre-activation of act[l]) for l >= 1, g[0] =
@@ -188,6 +221,7 @@ __global__ void __launch_bounds__(256, 1) k_train_bwd(TrainArgs T) {
     load_tile<G>(bufX, T.in, pos0, tid);
     __syncthreads();
     const size_t slot = (size_t)T.n * 64 * G::C;
+    __bf16* const mine = T.out + (size_t)pos0 * 64 * G::C;
     const size_t mslot = (size_t)(T.n / G::P) * 256;
     const uint4* mk = T.masks + (size_t)blockIdx.x * 256 + tid;
 #pragma unroll 1
@@ -195,15 +229,21 @@ __global__ void __launch_bounds__(256, 1) k_train_bwd(TrainArgs T) {
         // conv2 transposed: g[2 blk + 2] (X) -> g[2 blk + 1] (M), x ReLU bits of act[2 blk + 1] (mask slot 2 blk)
         uint4 m1 = mk[(size_t)(2 * blk) * mslot];
         unsigned b1[4] = {m1.x, m1.y, m1.z, m1.w};
-        conv_layer<0, G>(bufX, bufM, false, T.bias, WS, ap, w, r, h, tacc, EpTrain<G, true>{b1, true});
-        store_tile<G>(bufM, T.out + (size_t)(2 * blk + 1) * slot, pos0, tid);
+        // (g[2 blk + 2] = X, the block above's result, leaves in this layer's epilogue; g[L] came from HBM)
+        conv_layer<0, G>(bufX, bufM, false, T.bias, WS, ap, w, r, h, tacc,
+                         EpTrain<G, true>{b1, true, bufX, blk < T.n_layers / 2 - 1 ? mine + (size_t)(2 * blk + 2) * slot : nullptr, tid});
+        if constexpr (!kCopyInEpilogue<G>)
+            if (__bf16* cd = blk < T.n_layers / 2 - 1 ? mine + (size_t)(2 * blk + 2) * slot : nullptr) store_tile<G>(bufX, cd, 0, tid);
         // conv1 transposed: g[2 blk + 1] (M) -> X in place, + g[2 blk + 2] (the skip's gradient = what it overwrites),
         // x ReLU bits of act[2 blk] (mask slot 2 blk - 1; the tower's input act[0] has none: its ReLU is the stem's)
         uint4 m0 = blk > 0 ? mk[(size_t)(2 * blk - 1) * mslot] : make_uint4(0, 0, 0, 0);
         unsigned b0[4] = {m0.x, m0.y, m0.z, m0.w};
-        conv_layer<G::NCH % G::DEPTH, G>(bufM, bufX, true, T.bias, WS, ap, w, r, h, tacc, EpTrain<G, true>{b0, blk > 0});
-        store_tile<G>(bufX, T.out + (size_t)(2 * blk) * slot, pos0, tid);
+        conv_layer<G::NCH % G::DEPTH, G>(bufM, bufX, true, T.bias, WS, ap, w, r, h, tacc,
+                                         EpTrain<G, true>{b0, blk > 0, bufM, mine + (size_t)(2 * blk + 1) * slot, tid});
+        if constexpr (!kCopyInEpilogue<G>)
+            if (__bf16* cd = mine + (size_t)(2 * blk + 1) * slot) store_tile<G>(bufM, cd, 0, tid);
     }
+    store_tile<G>(bufX, mine, 0, tid);   // g[0]
 }
 
 // ---- weights: torch layout fp32 W[l][co][ci][tap] -> the two fragment streams (bf16, round to nearest even)

@@ -2,7 +2,7 @@
 """Where a training step's time goes: ms per Adam step of the az_loop net (64 channels, 4 blocks,
 batch 1024) with the residual tower on the hand-written HIP kernels (csrc/bz_train.hip) against stock PyTorch-ROCm
 autograd (MIOpen) -- eager / HIP-graph replay, fp32 / bf16 autocast, default / benchmarked MIOpen solvers, NCHW /
-channels-last -- plus the three tower kernels on their own.  python tools/bench_train.py [channels] [blocks] [batch] [--quick]"""
+channels-last -- plus the three tower kernels on their own.  python tools/bench_train.py [channels] [blocks] [batch] [--quick | --kernels-only]"""
 import os
 import sys
 import time
@@ -124,6 +124,8 @@ def ends_only():
 print(f"net {C} channels x {NB} blocks, batch {B}")
 print("tower kernels alone (csrc/bz_train.hip):")
 tower_only()
+if "--kernels-only" in sys.argv:
+    sys.exit(0)
 ends_only()
 run("bf16 graph  whole step on HIP kernels incl. Adam (10 launches)", True, True, False, False, kernels=True, step_kernels=True)
 run("bf16 graph  whole step on HIP kernels + torch's fused Adam", True, True, False, False, kernels=True, step_kernels=True, fused_adam=False)
