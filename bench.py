@@ -778,13 +778,17 @@ def run_reversi(ctx, args, B, sims, K, W):
 
 
 def main():
+    # multi-process GPU work on this image needs dmabuf IPC (the host driver does not support the legacy mode: RCCL set-up and
+    # tensor sharing otherwise fail with "hipIpcGetMemHandle: invalid argument"); the image exports this already -- make sure a
+    # launcher with a scrubbed environment still gets it, before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="reversi", choices=["reversi", "ttt", "net", "env", "train"],
                     help="reversi = BASELINE cfg 3 (default, the metric), ttt = cfg 2, net = cfg 5 (net forward only), "
-                         "env = the batched board-env step kernel alone")
+                         "env = the batched board-env step kernel alone, train = the training step of the benchmark net")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (default: BASELINE config)")
     ap.add_argument("--sims", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
