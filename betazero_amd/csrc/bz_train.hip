@@ -357,6 +357,21 @@ __device__ __forceinline__ void wg_stash(const u32x4 (&ra)[G::NLA], const u32x4 
     }
 }
 
+// diagnostic A/B: how far the k-step loop of the weight-gradient kernel is unrolled (tools/exp_wgrad_bounds.sh)
+#if (defined(BZ_EXP_WGRAD_NO_LDS_READS) || defined(BZ_EXP_WGRAD_NO_MFMA)) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_WGRAD_NO_LDS_READS / _NO_MFMA are diagnostic variants (timing only): build them through betazero_amd.build.build_variant()"
+#endif
+#if defined(BZ_EXP_WGRAD_NO_FETCH) && !defined(BZ_EXPERIMENT)
+#error "BZ_EXP_WGRAD_NO_FETCH is a diagnostic variant: build it through betazero_amd.build.build_variant()"
+#endif
+#ifdef BZ_EXP_WGRAD_UNROLL
+#ifndef BZ_EXPERIMENT
+#error "BZ_EXP_WGRAD_UNROLL is a diagnostic variant: build it through betazero_amd.build.build_variant()"
+#endif
+#define BZ_WGRAD_KK_UNROLL BZ_EXP_WGRAD_UNROLL
+#else
+#define BZ_WGRAD_KK_UNROLL 1
+#endif
 // the stages of one workgroup for the taps [T0, T1) of one wave (all waves run the same number of stages and barriers)
 template <int C, int T0, int T1>
 __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int tid, int lane, int mt, int nt0, int l, int split, int half,
@@ -389,10 +404,12 @@ __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int t
 #pragma unroll 1
     for (int s = s_begin; s < s_end; ++s) {
         const char* st = smem + ((s - s_begin) & 1) * G::STAGE;
+#ifndef BZ_EXP_WGRAD_NO_FETCH  // (diagnostic, timing only: every stage computes on the first stage's data -- what the kernel costs without its input stream)
         wg_fetch<G>(ra, rg, A, Gr, s + 1 < s_end ? s + 1 : s, half, tid);  // (the last stage re-reads itself: no branch around the registers)
+#endif
 #pragma unroll 1
         for (int p = 0; p < G::P2; ++p) {
-#pragma unroll 1
+#pragma unroll BZ_WGRAD_KK_UNROLL
             for (int kk = 0; kk < 4; ++kk) {  // k-step = board rows 2 kk (k half 0) and 2 kk + 1 (k half 1)
                 const int y = 2 * kk + hh;
                 bf16x8 bf[G::NTW];
@@ -410,9 +427,17 @@ __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int t
 #pragma unroll
                 for (int t = T0; t < T1; ++t) {  // tap t = 3 (dy + 1) + (dx + 1): the activations one row / one column over
                     const int i0 = 9 * (y + t / 3) + (q + t % 3 - 1) + 1, i1 = i0 + 4;
+#ifdef BZ_EXP_WGRAD_NO_LDS_READS   // (timing only: every tap multiplies the gradient fragment with itself -- the loop without its activation reads)
+                    const bf16x8 af = bf[t & 1];
+#else
                     const bf16x8 af = tr_pair(st, G::a_off(p, i0, mt) + inner, G::a_off(p, i1, mt) + inner);
+#endif
+#ifdef BZ_EXP_WGRAD_NO_MFMA        // (timing only: the reads alone, folded into one accumulator so that they stay)
+                    acc[t - T0][0][0] += (float)af[0] + (float)af[7];
+#else
 #pragma unroll
                     for (int nt = 0; nt < G::NTW; ++nt) acc[t - T0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t - T0][nt], 0, 0, 0);
+#endif
                 }
             }
         }
