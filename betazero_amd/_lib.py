@@ -120,6 +120,7 @@ _SIGS = {
     "bz_train_tower_fwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp]),
     "bz_train_tower_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "bz_train_wgrad_splits": (i32, [i32, i32, i32]),
+    "bz_train_wgrad_bias_rows": (i32, [i32, i32]),
     "bz_train_wgrad": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "bz_train_ends_sizes": (i32, [i32, i32, C.POINTER(i32)]),
     "bz_train_stem_fwd": (i32, [vp, i32, vp, vp, i32, vp, vp]),

@@ -17,6 +17,8 @@
 //    ds_read_b64_tr_b16 (the LDS transpose read of CDNA4; lane map verified on hardware by tools/probe/probe_tr_read.hip).
 //    A workgroup owns one row of taps (dy) of one layer and a slice of the batch; partial sums go to a scratch array
 //    that the caller reduces (a few MB).
+#include <type_traits>
+
 #include "bz_common.h"
 #include "bz_tower.h"
 
@@ -318,7 +320,8 @@ struct WgradArgs {
     const __bf16* acts;   // act[0 .. L-1]   [L][n][64][C]
     const __bf16* gs;     // g[1 .. L]       [L][n][64][C]
     float* partial;       // [L][S][9 taps][ci][co]
-    float* db_partial;    // [L][2 S][co]: sums of g over the slice's (position, cell), one per k half -- the bias gradient's partial sums
+    float* db_partial;    // [L][2 S MT][co]: sums of g over the slice's (position, cell) -- one row per k half and per wave of the
+                          // 4-tap group (each adds 8 / MT of a fragment's 8 cells): the bias gradient's partial sums
     int n, L, S;
 };
 
@@ -387,9 +390,11 @@ __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int t
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int nt = 0; nt < G::NTW; ++nt) acc[t][nt] = (f32x16)(0.0f);
-    // the bias gradient rides along in the waves that hold M-tile 0 (and tap group 0): a lane's gradient fragment is 8 cells
-    // of ONE output channel, so their sum is the lane's share of that channel's column sum (one float per N tile; the two k
-    // halves of a channel leave as two partial sums)
+    // the bias gradient rides along in the waves of the 4-tap group (two MFMAs per k-step fewer than the others: the stage
+    // ends at a barrier, so work on the 5-tap waves is work on the critical path -- the first version gave all of it to ONE
+    // of them, 32 VALU instructions and an early LDS wait per k-step).  A lane's gradient fragment is 8 cells of ONE output
+    // channel: wave mt adds cells 8 mt / MT .. of every fragment, so the waves' sums add up to the channel's column sum (one
+    // float per N tile and wave; the two k halves of a channel are two lanes)
     float bsum[G::NTW];
 #pragma unroll
     for (int nt = 0; nt < G::NTW; ++nt) bsum[nt] = 0.0f;
@@ -418,12 +423,6 @@ __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int t
                     const int i0 = 8 * y + q, i1 = i0 + 4;
                     bf[nt] = tr_pair(st, G::g_off(p, i0, nt0 + nt) + inner, G::g_off(p, i1, nt0 + nt) + inner);
                 }
-                if (do_bias) {
-#pragma unroll
-                    for (int nt = 0; nt < G::NTW; ++nt)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) bsum[nt] += (float)bf[nt][j];
-                }
 #pragma unroll
                 for (int t = T0; t < T1; ++t) {  // tap t = 3 (dy + 1) + (dx + 1): the activations one row / one column over
                     const int i0 = 9 * (y + t / 3) + (q + t % 3 - 1) + 1, i1 = i0 + 4;
@@ -438,6 +437,21 @@ __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int t
 #pragma unroll
                     for (int nt = 0; nt < G::NTW; ++nt) acc[t - T0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t - T0][nt], 0, 0, 0);
 #endif
+                }
+                if (do_bias) {   // (behind the taps: the adds issue while the last MFMAs run, and nothing waits early for bf)
+                    constexpr int JW = 8 / G::MT;
+                    auto add = [&](auto first) {   // (mt is wave-uniform: one scalar branch, compile-time element numbers)
+#pragma unroll
+                        for (int nt = 0; nt < G::NTW; ++nt)
+#pragma unroll
+                            for (int j = 0; j < JW; ++j) bsum[nt] += (float)bf[nt][decltype(first)::value + j];
+                    };
+                    if (mt == 0) add(std::integral_constant<int, 0>());
+                    else if (mt == 1) add(std::integral_constant<int, JW>());
+                    else if constexpr (G::MT == 4) {
+                        if (mt == 2) add(std::integral_constant<int, 2 * JW>());
+                        else add(std::integral_constant<int, 3 * JW>());
+                    }
                 }
             }
         }
@@ -456,9 +470,10 @@ __device__ __forceinline__ void wgrad_wave(const WgradArgs& T, char* smem, int t
                 const int ci = 32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h, co = 64 * half + 32 * (nt0 + nt) + r;
                 P[((size_t)t * C + ci) * C + co] = acc[t - T0][nt][i];
             }
-    if (do_bias) {  // lane (r, h): channel r of the tile, k half h -> partial sums [L][2 S][co]
+    if (do_bias) {  // lane (r, h): channel r of the tile, k half h -> partial sums [L][2 S MT][co]
 #pragma unroll
-        for (int nt = 0; nt < G::NTW; ++nt) T.db_partial[((size_t)l * 2 * T.S + 2 * split + h) * C + 64 * half + 32 * (nt0 + nt) + r] = bsum[nt];
+        for (int nt = 0; nt < G::NTW; ++nt)
+            T.db_partial[((size_t)l * 2 * T.S * G::MT + (size_t)(2 * split + h) * G::MT + mt) * C + 64 * half + 32 * (nt0 + nt) + r] = bsum[nt];
     }
 }
 
@@ -483,7 +498,7 @@ __global__ void __launch_bounds__(Wg<C>::NT, 1) k_train_wgrad(WgradArgs T) {
         *reinterpret_cast<uint4*>(smem + st * G::STAGE + o * 16) = make_uint4(0, 0, 0, 0);
     }
     if (s_begin >= s_end) return;  // (block-uniform; cannot happen: splits <= stages)
-    const bool do_bias = mt == 0 && tg == 0;  // wave-uniform
+    const bool do_bias = tg == G::TGN - 1;  // wave-uniform
     if constexpr (G::TGN == 1) {
         wgrad_wave<C, 0, 9>(T, smem, tid, lane, mt, nt0, l, split, half, s_begin, s_end, do_bias);
     } else {
@@ -509,6 +524,8 @@ BZ_EXPORT int64_t bz_train_mask_bytes(int32_t C, int32_t n_layers, int32_t n) {
     if (!P || n % P) { set_error("bz_train_mask_bytes: n must be a multiple of %d for C = %d", P, C); return -1; }
     return (int64_t)n_layers * (n / P) * 256 * 16 * (C == 64 ? 2 : 1);   // (C = 64: small batches run 4 positions per workgroup, twice the lanes)
 }
+/* rows of bz_train_wgrad's db_partial per layer */
+BZ_EXPORT int32_t bz_train_wgrad_bias_rows(int32_t C, int32_t splits) { return (C == 64 || C == 128) && splits >= 1 ? 2 * splits * (C / 32) : 0; }
 /* number of batch slices per layer of the weight-gradient kernel: n_layers * (C / 64) * S workgroups fill the chip once */
 BZ_EXPORT int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n) {
     if (!train_shape_ok(C, n_layers, n)) return 0;

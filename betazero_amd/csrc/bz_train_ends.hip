@@ -624,7 +624,8 @@ BZ_EXPORT int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_ten
     };
     typedef bz_train_tensors T;
     const int nS = stem_blocks(n), nH = heads_blocks(n), nW = heads_w_blocks(n), NP = 3 * C + 200;
-    add(Q->tower_b, &T::tower_b, nullptr, n_layers * C, 2 * Q->splits, C, C, 2 * Q->splits * C);
+    const int bias_rows = 2 * Q->splits * (C / 32);   // bz_train_wgrad_bias_rows()
+    add(Q->tower_b, &T::tower_b, nullptr, n_layers * C, bias_rows, C, C, bias_rows * C);
     add(Q->stem, &T::stem_w, nullptr, C * 18, nS, C * 19, C * 18, 0);
     add(Q->stem + C * 18, &T::stem_b, nullptr, C, nS, C * 19, C, 0);
     add(Q->heads, &T::pol_w, nullptr, 2 * C, nH, NP, 2 * C, 0);

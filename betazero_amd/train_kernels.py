@@ -44,7 +44,7 @@ class TowerPlan:
         self.wf_bwd = torch.zeros(nb, dtype=torch.uint8, device=dev)
         self.splits = L.bz_train_wgrad_splits(channels, n_layers, batch)
         self.partial = torch.zeros((n_layers, self.splits, 9, channels, channels), dtype=torch.float32, device=dev)
-        self.db_partial = torch.zeros((n_layers, 2 * self.splits, channels), dtype=torch.float32, device=dev)
+        self.db_partial = torch.zeros((n_layers, L.bz_train_wgrad_bias_rows(channels, self.splits), channels), dtype=torch.float32, device=dev)
         self.zeros_c = torch.zeros(channels, dtype=torch.float32, device=dev)
 
     def _stream(self):

@@ -358,10 +358,11 @@ int32_t bz_train_tower_fwd(const void* act0, const void* wf_fwd, const float* bi
 int32_t bz_train_tower_bwd(const void* g_top, const void* wf_bwd, const float* zeros_c, const void* masks, int32_t C,
                            int32_t n_layers, int32_t n, void* gs_out, void* stream);
 /* weight gradients: acts = act[0..L-1], gs = g[1..L], both [L][n][64][C].  partial (fp32) =
- * [L][splits][9 taps][C ci][C co] and db_partial (fp32) = [L][2 x splits][C]: the caller sums over the second axis of both
- * (bz_train_wgrad_splits()) and permutes the former to W's layout; the latter is the bias gradient (sum of
- * g[l + 1] over positions and cells). */
+ * [L][splits][9 taps][C ci][C co] and db_partial (fp32) = [L][bz_train_wgrad_bias_rows(C, splits)][C]: the caller sums over
+ * the second axis of both (bz_train_wgrad_splits()) and permutes the former to W's layout; the latter is the bias gradient
+ * (sum of g[l + 1] over positions and cells).  (bz_train_finish does both.) */
 int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n);
+int32_t bz_train_wgrad_bias_rows(int32_t C, int32_t splits);
 int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, int32_t n_layers, int32_t n, int32_t splits, float* partial,
                        float* db_partial, void* stream);
 
