@@ -116,6 +116,56 @@ __device__ __forceinline__ void epilogue_train(f32x16 (&acc)[G::MW][G::NU], char
         if (!BWD) bits[q] = word;
     }
 }
+// The same for the 16x16x32 path (Tw<128, 4, true>; lane map of bz_tower.h's epilogue16): lane (c, g) register 4 (2a + b) + i
+// of unit u holds channel 32 wt + 16 a + 4 g + i of board cell (row u, column c & 7) of position 2 b + (c >> 3).  ReLU bits:
+// word 2a + b, bits 4u .. 4u + 3 -- again 128 bits per lane and layer.
+template <class G, bool BWD>
+__device__ __forceinline__ void epilogue_train16(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt,
+                                                 int lane, unsigned (&bits)[4], bool use_bits) {
+    static_assert(G::MW == 1 && G::NU == 8 && G::M16, "the 16x16x32 path serves the row-tile shape of the 128-channel net");
+    const int c = lane & 15, g = lane >> 4, x = c & 7, pl = c >> 3;
+    int home2[2] = {pl * G::TILE + G::cell_at(0, x) + 8 * (g & 1), pl * G::TILE + G::cell_at(1, x) + 8 * (g & 1)};
+    asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int slot = G::pos16(4 * wt + 2 * a + (g >> 1), x);
+        const f32x4 bq = bias.q[0][a];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int q = 2 * a + b;
+            unsigned word = BWD ? bits[q] : 0u;
+#pragma unroll
+            for (int par = 0; par < 2; ++par)
+#pragma unroll
+                for (int u = par; u < G::NU; u += 2) {
+                    const int off = home2[par] + slot + b * 2 * G::TILE + (u & ~1) * G::ROWC * G::CELL;
+                    f32x4 v = {acc[0][u][4 * q], acc[0][u][4 * q + 1], acc[0][u][4 * q + 2], acc[0][u][4 * q + 3]};
+                    if (!BWD) v = v + bq;
+                    if (second) {
+                        bf16x4 sk = *reinterpret_cast<const bf16x4*>(out + off);
+                        v = v + __builtin_convertvector(sk, f32x4);
+                    }
+                    if (BWD) {
+                        const unsigned nib = use_bits ? (word >> (4 * u)) & 0xFu : 0xFu;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = (nib >> i) & 1u ? v[i] : 0.0f;
+                    }
+                    f32x2 vlo = {v[0], v[1]}, vhi = {v[2], v[3]};
+                    s16x2 lo = __builtin_bit_cast(s16x2, __builtin_convertvector(vlo, bf16x2));
+                    s16x2 hi = __builtin_bit_cast(s16x2, __builtin_convertvector(vhi, bf16x2));
+                    if (!BWD) {
+                        lo = __builtin_elementwise_max(lo, (s16x2)(0));
+                        hi = __builtin_elementwise_max(hi, (s16x2)(0));
+                        const unsigned nib = (lo[0] != 0 ? 1u : 0u) | (lo[1] != 0 ? 2u : 0u) | (hi[0] != 0 ? 4u : 0u) | (hi[1] != 0 ? 8u : 0u);
+                        word |= nib << (4 * u);
+                    }
+                    *reinterpret_cast<uint2*>(out + off) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+                }
+            if (!BWD) bits[q] = word;
+        }
+    }
+}
+
 // The copy-out of a layer's result (LDS tile -> HBM, what the weight gradients read) rides in the NEXT layer's epilogue on the
 // row-tile shapes: the tile is that layer's input, complete since the barrier and never written by its epilogue.  Issued
 // right behind a layer's own barrier the 16 stores per lane sit in front of the next K-loop's weight loads (vmcnt retires in
@@ -140,7 +190,8 @@ template <class G, bool BWD> struct EpTrain {
                                                int r, int h) const {
         if (kCopyInEpilogue<G> && copy_dst) store_tile<G>(copy_buf, copy_dst, 0, tid);
         unsigned (&b)[4] = *reinterpret_cast<unsigned (*)[4]>(bits);
-        epilogue_train<G, BWD>(acc, out, second, bias, wt0, r, h, b, use_bits);
+        if constexpr (G::M16) epilogue_train16<G, BWD>(acc, out, second, bias, wt0, 32 * h + r, b, use_bits);
+        else epilogue_train<G, BWD>(acc, out, second, bias, wt0, r, h, b, use_bits);
     }
 };
 
@@ -151,6 +202,14 @@ __device__ __forceinline__ void zero_halo(char* smem, int tid) {
         int k = i % ZC, j = (i / ZC) % 9, pb = i / (9 * ZC);
         *reinterpret_cast<uint4*>(smem + pb * G::TILE + j * G::ROWC * G::CELL + k * 16) = make_uint4(0, 0, 0, 0);
     }
+}
+template <class G>
+__device__ __forceinline__ void weights_prologue(WSets16<G>& WS, const uint4*& ap, int lane) {  // tap 0 of the first layer: KQ steps x 2 channel halves
+#pragma unroll
+    for (int kq = 0; kq < G::KQ; ++kq)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) WS.s[0][kq][a] = __builtin_bit_cast(bf16x8, ap[(kq * G::MT * 2 + a) * 64 + (unsigned)lane]);
+    ap += G::KQ * G::MT * 2 * 64;
 }
 template <class G>
 __device__ __forceinline__ void weights_prologue(WSets<G>& WS, const uint4*& ap, int lane) {
@@ -176,8 +235,8 @@ __global__ void __launch_bounds__(256, 1) k_train_fwd(TrainArgs T) {
     char* bufX = smem;
     char* bufM = smem + G::BUF;
     zero_halo<G>(smem, tid);
-    const uint4* ap = T.wf + (size_t)G::wt0(w) * 64;
-    WSets<G> WS;
+    const uint4* ap = T.wf + (size_t)G::wt0(w) * (G::M16 ? 2 * 64 : 64);
+    typename WSetsOf<G>::type WS;
     weights_prologue<G>(WS, ap, lane);
     load_tile<G>(bufX, T.in, pos0, tid);
     __syncthreads();
@@ -217,8 +276,8 @@ __global__ void __launch_bounds__(256, 1) k_train_bwd(TrainArgs T) {
     char* bufX = smem;
     char* bufM = smem + G::BUF;
     zero_halo<G>(smem, tid);
-    const uint4* ap = T.wf + (size_t)G::wt0(w) * 64;
-    WSets<G> WS;
+    const uint4* ap = T.wf + (size_t)G::wt0(w) * (G::M16 ? 2 * 64 : 64);
+    typename WSetsOf<G>::type WS;
     weights_prologue<G>(WS, ap, lane);
     load_tile<G>(bufX, T.in, pos0, tid);
     __syncthreads();
@@ -273,6 +332,34 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
     }
     wf_fwd[idx] = __builtin_bit_cast(uint4, f);
     wf_bwd[((((long long)(L - 1 - l) * 9 + t) * KC + kc) * MT + mt) * 64 + lane] = __builtin_bit_cast(uint4, b);
+}
+
+// the same two streams in the 16x16x32 path's fragment order (bz_tower.h; 128 channels): lane = 16 g + c
+//   forward : frag[((((l * 9 + t) * KQ + kq) * MT + wt) * 2 + a)][lane][j] = W[l][co = 32wt + 16a + c][ci = 32kq + 8g + j][t]
+//   backward: frag[(((((L-1-l) * 9 + t) * KQ + kq) * MT + wt) * 2 + a)][lane][j] = W[l][co = 32kq + 8g + j][ci = 32wt + 16a + c][8 - t]
+__global__ void __launch_bounds__(256) k_pack_weights16(const float* __restrict__ W, uint4* __restrict__ wf_fwd,
+                                                        uint4* __restrict__ wf_bwd, int L, int C) {
+    const int KQ = C / 32, MT = C / 32;
+    const long long total = (long long)L * 9 * KQ * MT * 2 * 64;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), c = lane & 15, g = lane >> 4;
+    long long rest = idx >> 6;
+    const int a = (int)(rest & 1); rest >>= 1;
+    const int wt = (int)(rest % MT); rest /= MT;
+    const int kq = (int)(rest % KQ); rest /= KQ;
+    const int t = (int)(rest % 9);
+    const int l = (int)(rest / 9);
+    const float* Wl = W + (size_t)l * C * C * 9;
+    bf16x8 f, b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * kq + 8 * g + j, m = 32 * wt + 16 * a + c;
+        f[j] = (__bf16)Wl[((size_t)m * C + k) * 9 + t];
+        b[j] = (__bf16)Wl[((size_t)k * C + m) * 9 + (8 - t)];
+    }
+    wf_fwd[idx] = __builtin_bit_cast(uint4, f);
+    wf_bwd[((((((long long)(L - 1 - l) * 9 + t) * KQ + kq) * MT + wt) * 2 + a) * 64) + lane] = __builtin_bit_cast(uint4, b);
 }
 
 // ---- backward-weights
@@ -537,9 +624,13 @@ BZ_EXPORT int32_t bz_train_wgrad_splits(int32_t C, int32_t n_layers, int32_t n) 
 
 BZ_EXPORT int32_t bz_train_pack_weights(const float* W, int32_t C, int32_t n_layers, void* wf_fwd, void* wf_bwd, void* stream) {
     BZ_REQUIRE(W && wf_fwd && wf_bwd && train_shape_ok(C, n_layers, 1), "bz_train_pack_weights: bad arguments (C = 64 or 128, n_layers even)");
-    const long long total = (long long)n_layers * 9 * (C / 16) * (C / 32) * 64;
-    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
-                       static_cast<uint4*>(wf_fwd), static_cast<uint4*>(wf_bwd), n_layers, C);
+    const long long total = (long long)n_layers * 9 * (C / 16) * (C / 32) * 64;   // (the same count in either fragment order)
+    if (C == 128)   // the 128-channel tower kernels run on the 16x16x32 path
+        hipLaunchKernelGGL(k_pack_weights16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                           static_cast<uint4*>(wf_fwd), static_cast<uint4*>(wf_bwd), n_layers, C);
+    else
+        hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                           static_cast<uint4*>(wf_fwd), static_cast<uint4*>(wf_bwd), n_layers, C);
     BZ_LAUNCH_CHECK("k_pack_weights");
     return BZ_OK;
 }
@@ -563,9 +654,11 @@ static int32_t train_tower(bool bwd, const void* in, const void* wf, const float
     // C = 64 keeps 8 positions per workgroup: n / 8 workgroups.  Below ~3/4 of the chip's 256 CUs, halve the tile instead
     // (4 positions per workgroup, 2 per wave: twice the weight stream per position, but twice the CUs at work)
     typedef Tw<64, 4> Tw64Half;
+    // 128 channels: the inference tower's 16x16x32 path (v_mfma_f32_16x16x32_bf16: same cycles, higher clock under load)
+    typedef Tw<128, 4, true> Tw128M16;
     if (C == 64 && n / 8 < 192) { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw64Half); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw64Half); }
     else if (C == 64) { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw<64>); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw<64>); }
-    else { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw<128>); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw<128>); }
+    else { if (bwd) BZ_TRAIN_LAUNCH(k_train_bwd, Tw128M16); else BZ_TRAIN_LAUNCH(k_train_fwd, Tw128M16); }
 #undef BZ_TRAIN_LAUNCH
     BZ_LAUNCH_CHECK("k_train_fwd / k_train_bwd");
     return BZ_OK;

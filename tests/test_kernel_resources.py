@@ -89,7 +89,7 @@ def test_training_kernels_do_not_spill(tmp_path):
     weight-gradient kernel keeps its staging registers in registers (an array of HIP's uint4 STRUCT had put them into
     scratch memory: 272 bytes per lane) and really reads both operands through the LDS transpose read"""
     res = _resources("bz_train.hip", tmp_path)
-    for parts in (("k_train_fwd", "Li64ELi8E"), ("k_train_fwd", "Li128ELi4E"), ("k_train_bwd", "Li64ELi8E"), ("k_train_bwd", "Li128ELi4E"),
+    for parts in (("k_train_fwd", "Li64ELi8E"), ("k_train_fwd", "Li128ELi4ELb1E"), ("k_train_bwd", "Li64ELi8E"), ("k_train_bwd", "Li128ELi4ELb1E"),
                   ("k_train_fwd", "Li64ELi4E"), ("k_train_bwd", "Li64ELi4E"),
                   ("k_train_wgrad", "Li64E"), ("k_train_wgrad", "Li128E")):
         k = _find(res, *parts)
