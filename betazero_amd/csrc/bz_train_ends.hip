@@ -131,23 +131,25 @@ __global__ __launch_bounds__(256) void k_train_stem_wgrad(const bz_train_batch* 
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int k = 0; k < 19; ++k) acc[s][k] = 0.0f;
-    for (int grp = blockIdx.x; grp * 4 < n; grp += gridDim.x) {
-        const int p = grp * 4 + wv;
+    // a wave takes HALF a position (32 cells) at a time: twice the waves of "one position per wave" -- two per SIMD at batch
+    // 1024 -- for a loop that is a chain of global loads and ~80 VALU instructions per cell (29 -> 21 us at 128 channels)
+    for (int grp = blockIdx.x; grp * 2 < n; grp += gridDim.x) {
+        const int item = grp * 4 + wv, p = item >> 1, c0 = 32 * (item & 1);
         __syncthreads();
         {
             unsigned m = 0u;
-            if (p < n) { const long long row = batch_row(B, p); m = nbhd_bits(B.own[row], B.opp[row], lane); }
+            if (p < n && lane < 32) { const long long row = batch_row(B, p); m = nbhd_bits(B.own[row], B.opp[row], c0 + lane); }
             nb[tid] = m;
         }
         __syncthreads();
         if (p < n) {
 #pragma unroll 4
-            for (int it = 0; it < 64 / CPW; ++it) {
-                const int cell = it * CPW + sub;
+            for (int it = 0; it < 32 / CPW; ++it) {
+                const int cl = it * CPW + sub, cell = c0 + cl;
                 const size_t at = ((size_t)p * 64 + cell) * PAIRS + pair;
                 const unsigned a = act0[at], g = g0[at];
                 const float glo = (a & 0x7fffu) ? bf_lo(g) : 0.0f, ghi = (a & 0x7fff0000u) ? bf_hi(g) : 0.0f;   // act0 >= 0: "> 0" = "not (+-)0"
-                const unsigned m = nb[64 * wv + cell];
+                const unsigned m = nb[64 * wv + cl];
 #pragma unroll
                 for (int k = 0; k < 18; ++k) {
                     const float f = (float)((m >> k) & 1u);
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void k_train_adam(AdamArgs A) {
 }
 
 bool ends_shape_ok(int C, int n) { return (C == 64 || C == 128) && n >= 4 && n % 4 == 0; }
-int stem_blocks(int n) { const int g = (n + 3) / 4; return g < 256 ? g : 256; }
+int stem_blocks(int n) { const int g = (n + 1) / 2; return g < 512 ? g : 512; }   // k_train_stem_wgrad: 4 half-positions per workgroup pass
 int heads_blocks(int n) { const int g = n / 4; return g < 256 ? g : 256; }
 int heads_w_blocks(int n) { const int g = (n + 7) / 8; return g < 128 ? g : 128; }
 
