@@ -422,8 +422,8 @@ __global__ __launch_bounds__(256) void k_train_heads_wgrad(const float* __restri
 // ---------------------------------------------------------------------------------------------------------------------
 // all partial sums of the step -> gradient tensors.  Workgroups [0, L * C): the tower's weight gradient, one (layer, ci)
 // each: sum over the batch slices of partial[l][s][tap][ci][co] (reads coalesced over co), written in torch's
-// [L][co][ci][3][3] through LDS (36-byte runs).  The rest: plain "dst[o] = sum_s src[s * stride + o]" jobs, 256 outputs
-// per workgroup.
+// [L][co][ci][3][3] through LDS (36-byte runs).  The rest: plain "dst[o] = sum_s src[s * stride + o]" jobs, 64 outputs
+// per workgroup (four thread groups share an output's partial vectors).
 struct ReduceJob {
     const float* src;
     float* dst;
@@ -483,11 +483,18 @@ __global__ __launch_bounds__(256) void k_train_finish(FinishArgs F) {
     const int b = blockIdx.x - F.L * C;
     int j = 0;
     while (j + 1 < F.n_jobs && b >= F.job[j + 1].block0) ++j;
+    // 64 outputs per workgroup, the partial vectors dealt to four thread groups (up to 512 of them per output: one thread
+    // walking them all -- 64 rounds of 8 loads -- made this kernel 10 us longer when the stem's gradient went to 512 partials)
     const ReduceJob J = F.job[j];
-    const int o = (b - J.block0) * 256 + tid;
-    if (o >= J.count) return;
-    const float* p = J.src + (size_t)(o / J.inner) * J.outer_stride + (o % J.inner);
-    J.dst[o] = strided_sum(p, J.parts, (size_t)J.stride);
+    const int o = (b - J.block0) * 64 + (tid & 63), slice = tid >> 6;
+    float sum = 0.0f;
+    if (o < J.count && slice < J.parts) {
+        const float* p = J.src + (size_t)(o / J.inner) * J.outer_stride + (o % J.inner) + (size_t)slice * J.stride;
+        sum = strided_sum(p, (J.parts - slice + 3) / 4, (size_t)4 * J.stride);
+    }
+    vals[tid] = sum;
+    __syncthreads();
+    if (tid < 64 && o < J.count) J.dst[o] = (vals[tid] + vals[tid + 64]) + (vals[tid + 128] + vals[tid + 192]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -622,7 +629,7 @@ BZ_EXPORT int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_ten
         ReduceJob& J = F.job[F.n_jobs++];
         J.src = src; J.dst = field ? G->*field : dst_plain;
         J.count = count; J.parts = parts; J.stride = stride; J.inner = inner; J.outer_stride = outer_stride; J.block0 = next_block;
-        next_block += (count + 255) / 256;
+        next_block += (count + 63) / 64;
     };
     typedef bz_train_tensors T;
     const int nS = stem_blocks(n), nH = heads_blocks(n), nW = heads_w_blocks(n), NP = 3 * C + 200;
