@@ -100,11 +100,11 @@ def test_training_kernels_do_not_spill(tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 def test_training_end_kernels_do_not_spill(tmp_path):
     """csrc/bz_train_ends.hip: the stem keeps its 8 x 18 weights, the stem's weight gradient its 2 x 19 and the FC
-    weight-gradient kernel its 49 accumulators in registers (no scratch); the heads kernel fits 4 waves per SIMD's worth
-    of registers although only its LDS (130 KB) decides the occupancy"""
+    weight-gradient kernel its 49 accumulators in registers (no scratch); the heads kernel holds a whole position's x tile
+    in flight (64 registers at 128 channels) and stays far below what its one workgroup per CU (130 KB of LDS) may use"""
     res = _resources("bz_train_ends.hip", tmp_path)
     for parts in (("k_train_stemILi64E",), ("k_train_stemILi128E",), ("k_train_stem_wgradILi64E",), ("k_train_stem_wgradILi128E",),
                   ("k_train_headsILi64E",), ("k_train_headsILi128E",), ("k_train_heads_wgrad",), ("k_train_finish",), ("k_train_adam",)):
         k = _find(res, *parts)
         assert k["vspill"] == 0 and k["sspill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (parts, k)
-    assert _find(res, "k_train_headsILi128E")["vgpr"] <= 128
+    assert _find(res, "k_train_headsILi128E")["vgpr"] <= 256
