@@ -4,10 +4,10 @@
 //   bitboards --k_train_stem--> act[0] --(bz_train.hip: forward)--> act[L] --k_train_heads--> losses, g[L]
 //   g[L] --(bz_train.hip: backward, weight gradients)--> g[0] --k_train_stem_wgrad--> d stem
 //   k_train_heads_wgrad: the two FC weight gradients whose reduction axis is the batch;  k_train_finish: every partial
-//   sum of the step -> the gradient tensors in torch's parameter layouts (one launch).
+//   sum of the step -> the gradient tensors in torch's parameter layouts (one launch);  k_train_adam: the update.
 //
-// With these a whole step is 9 launches + the optimiser instead of ~120 short torch kernels (casts, gathers, 1x1
-// "convolutions" as skinny GEMMs, soft-max, reductions), which at batch 1024 cost 2.5x the three tower kernels.
+// With these a whole step is 10 launches instead of ~120 short torch kernels (casts, gathers, 1x1 "convolutions" as
+// skinny GEMMs, soft-max, reductions, a multi-tensor optimiser), which at batch 1024 cost 2.5x the three tower kernels.
 // Everything here is HBM- / latency-bound small work: coalesced 16-byte accesses, LDS for the transposes, fp32
 // arithmetic on the bf16 activations the tower kernels store.  No MFMA on purpose (the largest product is 65 x 128).
 //

@@ -78,7 +78,7 @@ class GraphedTrainStep:
         # instead of MIOpen; default: whenever the module keeps its tower stacked (PolicyValueNet(fused_tower=True))
         if tower_kernels is None:
             tower_kernels = bool(getattr(module, "fused_tower", False))
-        # step_kernels: the WHOLE forward / losses / backward on the HIP kernels (train_kernels.StepPlan: 9 launches, no
+        # step_kernels: the WHOLE forward / losses / backward on the HIP kernels (train_kernels.StepPlan: 9 launches + Adam's, no
         # autograd -- stem, heads and losses too); default: whenever the tower kernels are on and the step runs in bf16.
         # step_kernels=False keeps stem / heads / losses in torch autograd around the tower kernels (the round-4 form).
         if step_kernels is None:

@@ -12,8 +12,9 @@ this raises.  PolicyValueNet uses these kernels when its forward() is handed a T
 forward() is the torch definition of the same net (CPU tests, the fp32 reference of the GPU tests).
 
 StepPlan goes one further: the WHOLE step's forward, losses and backward on kernels (csrc/bz_train_ends.hip adds the stem,
-the heads with their losses, and the reduction of every partial sum into the parameters' .grad tensors) -- 9 launches,
-no autograd; only the optimiser update is torch's.  That is what GraphedTrainStep captures by default."""
+the heads with their losses, the reduction of every partial sum into the parameters' .grad tensors, and Adam) -- 9
+launches for the gradients, a tenth for the update, no autograd, no torch kernel; the batch's rows are gathered by the
+kernels themselves.  That is what GraphedTrainStep captures by default."""
 import ctypes as ct
 
 import torch

@@ -368,7 +368,8 @@ int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, int32_t n_la
 
 /* ------------------------------------------------------------------------ */
 /* The two ends of the same step (csrc/bz_train_ends.hip), so that a whole   */
-/* step -- train.py:85-136's forward, loss, backward -- is 9 launches:       */
+/* step -- train.py:85-136's forward, loss, backward -- is 9 launches        */
+/* (10 with the optimiser):                                                   */
 /*   stem_fwd, pack_weights, tower_fwd, heads, tower_bwd, wgrad, stem_wgrad, */
 /*   heads_wgrad, finish (+ the Adam update as a tenth launch).  The net is     */
 /* betazero_amd/net.py's (SURVEY 8(d) "net"): every pointer below is one of   */
