@@ -460,12 +460,14 @@ def run_train(ctx, batch, K, W):
     assert all(np.isfinite(losses)) and losses[0] < float(first[0]), (losses, first)   # it is learning its 8 batches, not idling
     flop = 3 * (2 * 64 * 9 * C * C * 2 * NB + 2 * 64 * 9 * 2 * C) * batch
     ach = flop / (dev_ms * 1e-3) / 1e12
+    tr, tr_src = pmc_traffic(f"train_step@{C}x{NB}x{batch}", channels=C, blocks=NB, batch=batch)
     return {"metric": "train_steps_per_s", "value": K / dt, "unit": "steps/s", "n_gpus": ctx.world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"train_step_convnet6x128_batch{batch}_bf16", "optimizer": "Adam (as its own kernel)",
                        "launches_per_step": 10, "loss_first_last": [float(first[0]), losses[0]]},
             "roofline": {"bound": "mfma", "kernel": "k_train_fwd + k_train_bwd + k_train_wgrad (+ the six end kernels)",
-                         "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+                         "traffic": tr, "traffic_source": tr_src,
                          "avg_launch_ms": dev_ms, "flop_per_launch": flop,
                          "note": "whole step (10 kernels) timed with events on the launch stream; flop = convolution work only"}}
 

@@ -55,6 +55,22 @@ for key, name, kern, shape, cmd in (
         except Exception:
             pass
     out[key] = ent
+# the training step: the sum over its ten kernels (tools/prof_train_pmc.sh: the kernels launched eagerly, counters per kernel)
+for key, pre, shape in (("train_step@128x6x1024", "train128", {"channels": 128, "blocks": 6, "batch": 1024}),
+                        ("train_step@64x4x1024", "train64", {"channels": 64, "blocks": 4, "batch": 1024})):
+    fp, wp = os.path.join(src, f"{tag}_{pre}_fetch_pmc.csv"), os.path.join(src, f"{tag}_{pre}_write_pmc.csv")
+    if not (os.path.exists(fp) and os.path.exists(wp)):
+        continue
+    per = {}
+    for path, col in ((fp, "fetch_kb"), (wp, "write_kb")):
+        for r in csv.DictReader(open(path)):
+            if ("k_train_" in r["Kernel"] or "k_pack_weights" in r["Kernel"]) and r["Counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                per.setdefault(r["Kernel"].split("(")[0], {})[col] = float(r["MeanValue"])
+    if not per or any(len(v) != 2 for v in per.values()):
+        continue
+    tot = sum(2 * v["fetch_kb"] + v["write_kb"] for v in per.values()) * 1024
+    out[key] = dict(shape, hbm_bytes_per_launch=int(tot), kernels={k: int((2 * v["fetch_kb"] + v["write_kb"]) * 1024) for k, v in per.items()},
+                    note="one launch = one step = the sum over its ten kernels", command=f"python3 tools/prof_train_kernels.py {shape['channels']} {shape['blocks']} {shape['batch']}")
 path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
 json.dump(out, open(path, "w"), indent=1)
 print(open(path).read())
