@@ -50,9 +50,6 @@ __device__ __forceinline__ void load_tile(char* buf, const __bf16* src, int pos0
         *reinterpret_cast<uint4*>(buf + p * G::TILE + G::cell_off(p, c, k)) = s[i];
     }
 }
-#if defined(BZ_EXP_EPILOGUE_STORES) && !defined(BZ_EXPERIMENT)
-#error "BZ_EXP_EPILOGUE_STORES is a diagnostic variant (for A/B): build it through betazero_amd.build.build_variant()"
-#endif
 #if defined(BZ_EXP_COPY_AFTER_BARRIER) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_COPY_AFTER_BARRIER is a diagnostic variant (the round-4 placement of the copy-out, for A/B): build it through betazero_amd.build.build_variant()"
 #endif
@@ -124,14 +121,11 @@ __device__ __forceinline__ void epilogue_train(f32x16 (&acc)[G::MW][G::NU], char
 // word 2a + b, bits 4u .. 4u + 3 -- again 128 bits per lane and layer.
 template <class G, bool BWD>
 __device__ __forceinline__ void epilogue_train16(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt,
-                                                 int lane, unsigned (&bits)[4], bool use_bits, __bf16* gdst) {
+                                                 int lane, unsigned (&bits)[4], bool use_bits) {
     static_assert(G::MW == 1 && G::NU == 8 && G::M16, "the 16x16x32 path serves the row-tile shape of the 128-channel net");
     const int c = lane & 15, g = lane >> 4, x = c & 7, pl = c >> 3;
     int home2[2] = {pl * G::TILE + G::cell_at(0, x) + 8 * (g & 1), pl * G::TILE + G::cell_at(1, x) + 8 * (g & 1)};
     asm volatile("" : "+v"(home2[0]), "+v"(home2[1]));
-    // the same 8 bytes go to HBM (what the weight gradients read), straight from the registers: [position][cell][channel],
-    // the lane's first element = position pl, cell (row 0, column x), channel 32 wt + 4 g; + (2 b positions, row u, 16 a channels)
-    __bf16* const glane = gdst + ((size_t)(pl * 64 + x) * G::C + 32 * wt + 4 * g);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int slot = G::pos16(4 * wt + 2 * a + (g >> 1), x);
@@ -165,9 +159,7 @@ __device__ __forceinline__ void epilogue_train16(f32x16 (&acc)[G::MW][G::NU], ch
                         const unsigned nib = (lo[0] != 0 ? 1u : 0u) | (lo[1] != 0 ? 2u : 0u) | (hi[0] != 0 ? 4u : 0u) | (hi[1] != 0 ? 8u : 0u);
                         word |= nib << (4 * u);
                     }
-                    const uint2 val = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
-                    *reinterpret_cast<uint2*>(out + off) = val;
-                    if (gdst) *reinterpret_cast<uint2*>(glane + ((size_t)(2 * b * 64 + 8 * u) * G::C + 16 * a)) = val;
+                    *reinterpret_cast<uint2*>(out + off) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
                 }
             if (!BWD) bits[q] = word;
         }
@@ -188,27 +180,20 @@ template <class G> constexpr bool kCopyInEpilogue =
 #else
     G::ROWT;
 #endif
-// Rejected (kept as a diagnostic variant): a layer's result stored to HBM from its own epilogue, straight from the registers
-// that go to LDS -- no copy pass at all, but 8 bytes per lane and store, 32-byte runs per cell: forward 190 -> 208 us,
-// backward-data 168 -> 183 us at 128 channels (profiles/r04_exp_epilogue_stores.txt).  The copy pass writes whole 1-KB rows.
-template <class G> constexpr bool kStoreFromEpilogue =
-#ifdef BZ_EXP_EPILOGUE_STORES
-    G::M16;
-#else
-    false;
-#endif
+// (Rejected, code removed: a layer's result stored to HBM from its own epilogue, straight from the registers that go to LDS --
+// no copy pass at all, but 8 bytes per lane and store, 32-byte runs per cell: 10 % slower, profiles/r04_exp_epilogue_stores.txt;
+// and the copy pass dealt to the next K-loop's sub-steps: 5 % slower, profiles/r04_exp_kloop_copy.txt.)
 template <class G, bool BWD> struct EpTrain {
     unsigned* bits;   // the lane's 128 ReLU bits of this layer (FWD: written, BWD: read)
     bool use_bits;
     const char* copy_buf;   // the workgroup's LDS tile to copy out first (this layer's input) ...
     __bf16* copy_dst;       // ... to here (the workgroup's first position of the destination tensor), or null: nothing to copy
-    __bf16* direct;         // kStoreFromEpilogue: where THIS layer's result goes (the workgroup's first position)
     int tid;
     __device__ __forceinline__ void operator()(f32x16 (&acc)[G::MW][G::NU], char* out, bool second, const Bias<G>& bias, int wt0,
                                                int r, int h) const {
-        if (!kStoreFromEpilogue<G> && kCopyInEpilogue<G> && copy_dst) store_tile<G>(copy_buf, copy_dst, 0, tid);
+        if (kCopyInEpilogue<G> && copy_dst) store_tile<G>(copy_buf, copy_dst, 0, tid);
         unsigned (&b)[4] = *reinterpret_cast<unsigned (*)[4]>(bits);
-        if constexpr (G::M16) epilogue_train16<G, BWD>(acc, out, second, bias, wt0, 32 * h + r, b, use_bits, kStoreFromEpilogue<G> ? direct : nullptr);
+        if constexpr (G::M16) epilogue_train16<G, BWD>(acc, out, second, bias, wt0, 32 * h + r, b, use_bits);
         else epilogue_train<G, BWD>(acc, out, second, bias, wt0, r, h, b, use_bits);
     }
 };
@@ -267,17 +252,17 @@ __global__ void __launch_bounds__(256, 1) k_train_fwd(TrainArgs T) {
         unsigned bits[4];
         // (act[2 blk] = X, the previous block's result, leaves in this layer's epilogue; act[0] came from HBM)
         conv_layer<0, G>(bufX, bufM, false, T.bias + (size_t)(2 * blk) * G::C, WS, ap, w, r, h, tacc,
-                         EpTrain<G, false>{bits, true, bufX, blk > 0 ? mine + (size_t)(2 * blk - 1) * slot : nullptr, mine + (size_t)(2 * blk) * slot, tid});
-        if constexpr (!kCopyInEpilogue<G> && !kStoreFromEpilogue<G>)
+                         EpTrain<G, false>{bits, true, bufX, blk > 0 ? mine + (size_t)(2 * blk - 1) * slot : nullptr, tid});
+        if constexpr (!kCopyInEpilogue<G>)
             if (__bf16* cd = blk > 0 ? mine + (size_t)(2 * blk - 1) * slot : nullptr) store_tile<G>(bufX, cd, 0, tid);
         mk[(size_t)(2 * blk) * mslot] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
         conv_layer<G::NCH % G::DEPTH, G>(bufM, bufX, true, T.bias + (size_t)(2 * blk + 1) * G::C, WS, ap, w, r, h, tacc,
-                                         EpTrain<G, false>{bits, true, bufM, mine + (size_t)(2 * blk) * slot, mine + (size_t)(2 * blk + 1) * slot, tid});
-        if constexpr (!kCopyInEpilogue<G> && !kStoreFromEpilogue<G>)
+                                         EpTrain<G, false>{bits, true, bufM, mine + (size_t)(2 * blk) * slot, tid});
+        if constexpr (!kCopyInEpilogue<G>)
             if (__bf16* cd = mine + (size_t)(2 * blk) * slot) store_tile<G>(bufM, cd, 0, tid);
         mk[(size_t)(2 * blk + 1) * mslot] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
     }
-    if constexpr (!kStoreFromEpilogue<G>) store_tile<G>(bufX, mine + (size_t)(T.n_layers - 1) * slot, 0, tid);
+    store_tile<G>(bufX, mine + (size_t)(T.n_layers - 1) * slot, 0, tid);
 }
 
 // backward-data: g[L] (HBM) -> g[L-1 .. 0] (HBM).  g[l] = d(loss)/d(pre-activation of act[l]) for l >= 1, g[0] =
@@ -310,19 +295,19 @@ __global__ void __launch_bounds__(256, 1) k_train_bwd(TrainArgs T) {
         unsigned b1[4] = {m1.x, m1.y, m1.z, m1.w};
         // (g[2 blk + 2] = X, the block above's result, leaves in this layer's epilogue; g[L] came from HBM)
         conv_layer<0, G>(bufX, bufM, false, T.bias, WS, ap, w, r, h, tacc,
-                         EpTrain<G, true>{b1, true, bufX, blk < T.n_layers / 2 - 1 ? mine + (size_t)(2 * blk + 2) * slot : nullptr, mine + (size_t)(2 * blk + 1) * slot, tid});
-        if constexpr (!kCopyInEpilogue<G> && !kStoreFromEpilogue<G>)
+                         EpTrain<G, true>{b1, true, bufX, blk < T.n_layers / 2 - 1 ? mine + (size_t)(2 * blk + 2) * slot : nullptr, tid});
+        if constexpr (!kCopyInEpilogue<G>)
             if (__bf16* cd = blk < T.n_layers / 2 - 1 ? mine + (size_t)(2 * blk + 2) * slot : nullptr) store_tile<G>(bufX, cd, 0, tid);
         // conv1 transposed: g[2 blk + 1] (M) -> X in place, + g[2 blk + 2] (the skip's gradient = what it overwrites),
         // x ReLU bits of act[2 blk] (mask slot 2 blk - 1; the tower's input act[0] has none: its ReLU is the stem's)
         uint4 m0 = blk > 0 ? mk[(size_t)(2 * blk - 1) * mslot] : make_uint4(0, 0, 0, 0);
         unsigned b0[4] = {m0.x, m0.y, m0.z, m0.w};
         conv_layer<G::NCH % G::DEPTH, G>(bufM, bufX, true, T.bias, WS, ap, w, r, h, tacc,
-                                         EpTrain<G, true>{b0, blk > 0, bufM, mine + (size_t)(2 * blk + 1) * slot, mine + (size_t)(2 * blk) * slot, tid});
-        if constexpr (!kCopyInEpilogue<G> && !kStoreFromEpilogue<G>)
+                                         EpTrain<G, true>{b0, blk > 0, bufM, mine + (size_t)(2 * blk + 1) * slot, tid});
+        if constexpr (!kCopyInEpilogue<G>)
             if (__bf16* cd = mine + (size_t)(2 * blk + 1) * slot) store_tile<G>(bufM, cd, 0, tid);
     }
-    if constexpr (!kStoreFromEpilogue<G>) store_tile<G>(bufX, mine, 0, tid);   // g[0]
+    store_tile<G>(bufX, mine, 0, tid);   // g[0]
 }
 
 // ---- weights: torch layout fp32 W[l][co][ci][tap] -> the two fragment streams (bf16, round to nearest even)
