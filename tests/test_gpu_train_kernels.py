@@ -340,6 +340,26 @@ def test_step_gathers_its_batch_rows_itself_and_clamps_bad_indices():
     c = plan.grads(own, opp, pi, z, bad).clone()
     d = plan.grads(own, opp, pi, z, good).clone()
     assert torch.equal(c, d) and not torch.equal(c, a)
+    # another data set (new tensors, new addresses): only the descriptor changes -- a captured graph would keep working
+    own2, opp2, pi2, z2 = (t.roll(7, 0).contiguous() for t in (own, opp, pi, z))
+    e = plan.grads(own2, opp2, pi2, z2, idx).clone()
+    f = plan.grads(own, opp, pi, z, (idx - 7) % rows).clone()      # the same rows of the original tensors
+    assert torch.equal(e, f) and not torch.equal(e, a)
+    graph = torch.cuda.CUDAGraph()
+    plan.set_batch(own, opp, pi, z, idx)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.launch()
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        plan.launch()
+    graph.replay()
+    assert torch.equal(plan.losses, a)
+    plan.set_batch(own2, opp2, pi2, z2, idx)                       # ... and it does: same graph, other data set
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.losses, e)
     with pytest.raises(ValueError):
         plan.set_batch(own, opp, pi, z, idx[:8])              # not a whole batch of indices
     with pytest.raises(ValueError):
