@@ -55,6 +55,18 @@ def test_argument_validation_without_gpu():
     assert L.bz_engine_workspace_bytes(None) == -1
     cfg = _lib.EngineCfg(1, 4, 8, 0, 1.5, 0, 0, 1, 64, 0, 0, 0, 4, 0, 0.0, 0.0, 0)
     assert L.bz_engine_workspace_bytes(C.byref(cfg)) > 0
+    # the training entry points refuse shapes they are not built for, and null pointers, before anything is launched
+    sizes = (C.c_int32 * 6)()
+    assert L.bz_train_ends_sizes(96, 64, sizes) == _lib.BZ_EINVAL and b"64 or 128" in L.bz_last_error()
+    assert L.bz_train_ends_sizes(64, 6, sizes) == _lib.BZ_EINVAL                      # the batch must be a multiple of 4
+    assert L.bz_train_ends_sizes(128, 1024, sizes) == _lib.BZ_OK and list(sizes) == [512, 128 * 19, 256, 3 * 128 + 200, 128, 65 * 128 + 64 * 64]
+    assert L.bz_train_wgrad_bias_rows(128, 10) == 80 and L.bz_train_wgrad_bias_rows(96, 10) == 0
+    assert L.bz_train_wf_bytes(96, 4) == -1 and L.bz_train_wf_bytes(128, 3) == -1      # width; odd number of conv layers
+    assert L.bz_train_stem_fwd(None, 64, None, None, 64, None, None) == _lib.BZ_EINVAL
+    assert L.bz_train_heads(None, None, 64, 64, 64, None, None, None, None, None, None, None) == _lib.BZ_EINVAL
+    assert L.bz_train_heads_wgrad(None, None, None, 64, 65, None, None) == _lib.BZ_EINVAL and b"value_hidden" in L.bz_last_error()
+    assert L.bz_train_finish(None, None, 64, 4, 64, 64, None, None, None) == _lib.BZ_EINVAL
+    assert L.bz_train_pack_weights(None, 64, 4, None, None, None) == _lib.BZ_EINVAL
 
 
 @pytest.mark.skipif(_lib.lib().bz_device_count() > 0, reason="CPU-only check")
