@@ -1,7 +1,8 @@
 // bz_train.hip -- the residual tower's TRAINING step on gfx950: forward with saved activations, backward-data and
 // backward-weights of its 2 NB conv3x3 layers as hand-written bf16 MFMA kernels (the loop they
 // serve has the shape of src/tic_tac_toe/SL/train.py:85-136 -- forward, loss, backward, Adam step -- with this net in
-// place of the reference's MLP).  Stem, heads, losses and the optimiser stay in torch; fp32 master weights.
+// place of the reference's MLP).  Stem, heads, losses, the gradient reduction and the optimiser are the kernels of
+// bz_train_ends.hip; fp32 master weights.
 //
 //  * k_train_fwd<G>:  the inference tower's K-loop and LDS image (bz_tower.h: P positions resident in LDS across all
 //    layers, weights streamed fragment-major from L2), fed from HBM instead of the stem, with every layer's output copied

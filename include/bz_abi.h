@@ -333,8 +333,9 @@ int32_t bz_engine_sum_counters(bz_engine* e, void* stream);
 /* bf16 MFMA kernels for forward-with-saved-activations, backward-data and   */
 /* backward-weights of its n_layers = 2 NB conv3x3 layers.  The loop they    */
 /* serve has the shape of src/tic_tac_toe/SL/train.py:85-136 (forward, loss, */
-/* backward, Adam step); stem, heads, losses and the optimiser stay with the */
-/* caller (torch), as do the fp32 master weights.  C = 64 or 128.            */
+/* backward, Adam step); stem, heads, losses and the optimiser are the next   */
+/* section's entry points (or the caller's own); the fp32 master weights stay */
+/* with the caller.  C = 64 or 128.                                           */
 /*                                                                           */
 /* Tensors (device, bf16 unless noted), n = batch (a multiple of             */
 /* bz_train_positions_per_workgroup(C)):                                     */
