@@ -626,7 +626,7 @@ def run_reversi(ctx, args, B, sims, K, W):
             L.bz_profile_reserve(_lib.PROF_SLOTS.index(slot), per)
     L.bz_profile_enable(1 if prof_on else 0)
     buf = None
-    if ctx.world > 1:
+    if ctx.dist:
         # both ends of the one exchange exist before the clock starts.  The packed block holds the finished games only;
         # its capacity (the same on every rank) bounds what W + K steps of the steady-state pool can finish: a slot
         # finishes a game every ~58 moves -- sized for one every 50, plus 10 steps of slack; a whole iteration: every slot.
@@ -649,7 +649,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     t_issued = time.perf_counter() - t0     # the host has queued every launch of the K steps
     c1t = time.thread_time()
     ctx.sync()
-    if ctx.world > 1:  # the one exchange step: pool the finished games' (s, pi, z) -- pack kernels + ONE all-gather
+    if ctx.dist:  # the one exchange step: pool the finished games' (s, pi, z) -- pack kernels + ONE all-gather
         bd.gather_packed(sp, buffers=buf)
     ctx.barrier()
     dt = time.perf_counter() - t0
@@ -668,7 +668,7 @@ def run_reversi(ctx, args, B, sims, K, W):
             "launch_cpu_frac_while_issuing": (c1t - c0t) / max(t_issued, 1e-9),
             "launches_per_s": K * NS * (2 * sims + 4) / dt if steady else None}
     pooled = None
-    if ctx.world > 1:  # untimed: what the collective delivered (each rank's header carries its own counts)
+    if ctx.dist:  # untimed: what the collective delivered (each rank's header carries its own counts)
         heads = [packed_block_header(buf.out[r], strict=False) for r in range(ctx.world)]
         pooled = {"bytes_received_per_rank": int(buf.out.numel()), "block_bytes_per_rank": int(buf.nbytes),
                   "cap_rows": int(buf.cap_rows), "rows": int(sum(h["n_rows"] for h in heads)),
@@ -682,7 +682,7 @@ def run_reversi(ctx, args, B, sims, K, W):
         dt, games = float(tmax[0]), float(tsum[1])
     cnt = sp.counters()
     ranks = None
-    if ctx.world > 1:  # untimed: which device every rank really held, what it finished and how long it took
+    if ctx.dist:  # untimed: which device every rank really held, what it finished and how long it took
         pr = torch.cuda.get_device_properties(ctx.local)
         mine = {"rank": ctx.rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device_index": ctx.local,
                 "device_name": pr.name, "device_uuid": str(getattr(pr, "uuid", "")),
@@ -811,6 +811,10 @@ def main():
                     help="N > 1: weak = --games per GPU (default, the headline); strong = --games in total, split over the ranks")
     ap.add_argument("--reuse-subtree", action="store_true", help="supplementary: keep the chosen child's subtree (DESIGN 3.10)")
     ap.add_argument("--dirichlet-eps", type=float, default=0.0, help="supplementary: root noise weight (alpha 0.5; DESIGN 3.9)")
+    ap.add_argument("--force-collective", action="store_true", default=os.environ.get("BZ_BENCH_FORCE_DIST") == "1",
+                    help="take the N > 1 path at ANY world size, 1 included (also BZ_BENCH_FORCE_DIST=1): process group on the chosen "
+                         "backend (nccl = RCCL with device_id), GatherBuffers on the device, pack kernels, the one all_gather_into_tensor, "
+                         "the device-side all_reduces, ranks.per_rank, pooled -- so that the multi-GPU branch can be run on a one-GPU box")
     ap.add_argument("--ttt-lanes", type=int, default=0, choices=[-1, 0, 1, 2, 4, 8],
                     help="--workload ttt: lanes per game of the fused search (bz_engine_cfg.ttt_lanes; 0 = default, -1 = generic kernel)")
     args = ap.parse_args()
@@ -818,6 +822,12 @@ def main():
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        if args.force_collective:  # a world of one rank, no launcher needed: this process is rank 0 of 1
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                               "MASTER_PORT": str(s.getsockname()[1])})
+            s.close()
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: start me as "
                  f"`python bench.py --gpus N` or under torchrun with --nproc-per-node equal to --gpus")
@@ -847,7 +857,8 @@ def main():
     ctx.dev = f"cuda:{local}"
     ctx.local = local
     torch.cuda.set_device(local)
-    if ctx.world > 1:
+    ctx.dist = ctx.world > 1 or args.force_collective   # the multi-rank path (always at N > 1; on request at N = 1)
+    if ctx.dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if ctx.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(ctx.dev))
@@ -857,7 +868,7 @@ def main():
     ctx.sync = torch.cuda.synchronize
 
     def barrier():
-        if ctx.world > 1:
+        if ctx.dist:
             dist.barrier()
         torch.cuda.synchronize()
     ctx.barrier = barrier
@@ -931,10 +942,12 @@ def main():
                     out["secondary"]["cfg1"] = c1
                 note("cpu baseline done")
     if ctx.rank == 0:
-        out["n_gpus"] = dist.get_world_size() if ctx.world > 1 else 1
+        out["n_gpus"] = dist.get_world_size() if ctx.dist else 1
         assert out["n_gpus"] == args.gpus
+        if args.force_collective:
+            out["forced_collective_path"] = True
         print(json.dumps(out))
-    if ctx.world > 1:
+    if ctx.dist:
         dist.destroy_process_group()
 
 

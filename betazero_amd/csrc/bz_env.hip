@@ -159,10 +159,12 @@ BZ_EXPORT int32_t bz_device_count(void) {
     return n;
 }
 
-static bool size_ok(int32_t s) { return s == 4 || s == 6 || s == 8; }
+// the rule entry points take every size whose cells fit bit = 8*row+col (reversi_board.py:4-14 is generic); the engine's
+// games (bz_engine_cfg.game) and the arena stay 4 / 6 / 8
+static bool size_ok(int32_t s) { return s >= 1 && s <= 8; }
 
 BZ_EXPORT int32_t bz_reversi_legal(uint64_t own, uint64_t opp, int32_t size, uint64_t* legal) {
-    BZ_REQUIRE(size_ok(size) && legal, "bz_reversi_legal: size must be 4, 6 or 8");
+    BZ_REQUIRE(size_ok(size) && legal, "bz_reversi_legal: size must be 1..8");
     *legal = rev_legal(own, opp, rev_valid(size));
     return BZ_OK;
 }
@@ -455,7 +457,7 @@ BZ_EXPORT int32_t bz_reversi_step_batch_sized(const uint64_t* own, const uint64_
                                               uint8_t* status, int8_t* winner, void* stream) {
     BZ_REQUIRE(n >= 0 && own && opp && action && own_next && opp_next && legal_next && status && winner,
                "bz_reversi_step_batch: null pointer");
-    BZ_REQUIRE(size_ok(size), "bz_reversi_step_batch: size must be 4, 6 or 8");
+    BZ_REQUIRE(size_ok(size), "bz_reversi_step_batch: size must be 1..8");
     if (n == 0) return BZ_OK;
     BZ_REQUIRE((((uintptr_t)own | (uintptr_t)opp | (uintptr_t)own_next | (uintptr_t)opp_next | (uintptr_t)legal_next) & 15) == 0 &&
                    (((uintptr_t)action | (uintptr_t)status | (uintptr_t)winner) & 3) == 0,

@@ -25,6 +25,11 @@ class TicTacToeBoard:
         o = int((_W3 * (self.board == -1)).sum())
         return (x, o) if player == 1 else (o, x)
 
+    def _other(self):
+        """cells that are occupied by neither X nor O: make_move stores whatever `player` is (tic_tac_toe_board.py:28)
+        and every non-zero cell is occupied afterwards (:21, :39, :43)"""
+        return int((_W3 * ((self.board != 0) & (self.board != 1) & (self.board != -1))).sum())
+
     def __str__(self):  # tic_tac_toe_board.py:7-15
         out_str = ""
         for i, row in enumerate(self.board):
@@ -44,11 +49,13 @@ class TicTacToeBoard:
         x, o = self.bits()
         out = C.c_uint32()
         _lib.check(_lib.lib().bz_ttt_legal(x, o, C.byref(out)))
-        return bool(out.value >> (3 * row + col) & 1)
+        return bool((out.value & ~self._other()) >> (3 * row + col) & 1)
 
     def make_move(self, row, col, player):
         x, o = self.bits()
         out = C.c_uint32()
+        if not self.is_valid_move(row, col):
+            raise ValueError("Invalid move")
         _lib.check(_lib.lib().bz_ttt_apply(x, o, int(row), int(col), C.byref(out)))  # ValueError("Invalid move")
         new_board = TicTacToeBoard(self.board)
         new_board.board[row][col] = player  # the reference stores whatever `player` is
@@ -58,13 +65,16 @@ class TicTacToeBoard:
         x, o = self.bits()
         over, w = C.c_int32(), C.c_int32()
         _lib.check(_lib.lib().bz_ttt_game_over(x, o, C.byref(over), C.byref(w)))
+        if not over.value and (x | o | self._other()) == 0x1FF:
+            return True, 0  # full, counting the cells that hold something else (tic_tac_toe_board.py:38-39)
         return (True, w.value) if over.value else (False, None)
 
     def generate_possible_moves(self):
         x, o = self.bits()
         out = C.c_uint32()
         _lib.check(_lib.lib().bz_ttt_legal(x, o, C.byref(out)))
-        return [(i, j) for i in range(3) for j in range(3) if out.value >> (3 * i + j) & 1]
+        m = out.value & ~self._other()
+        return [(i, j) for i in range(3) for j in range(3) if m >> (3 * i + j) & 1]
 
 
 class TicTacToeHeadless:

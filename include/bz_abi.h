@@ -16,8 +16,11 @@
  *    They are asynchronous on that stream.  The library never allocates or
  *    frees device memory the caller sees: the caller passes a workspace sized
  *    by the matching *_workspace_bytes() query.
- *  - Bitboards: Reversi bit = 8*row+col for every board size (4, 6, 8);
- *    Tic-tac-toe bit = 3*row+col.  "own" = stones of the side to move,
+ *  - Bitboards: Reversi bit = 8*row+col for every board size (the rule entry
+ *    points -- bz_reversi_legal / _apply / _game_over / _step_batch_sized --
+ *    take size 1..8, every size of the reference's generic constructor,
+ *    reversi_board.py:4-14, whose cells fit 64 bits; the engine's games and the
+ *    arena are 4, 6 and 8); Tic-tac-toe bit = 3*row+col.  "own" = stones of the side to move,
  *    "opp" = the other side (the side-to-move canonical form of
  *    src/tic_tac_toe/SL/generate_training_games.py:17-18).
  *  - Action index = size*row+col as in the reference's CSV flattening
@@ -59,7 +62,10 @@ int32_t bz_device_count(void);
 /* the kernels use).  Back the API-compatible single-board classes.          */
 /* ------------------------------------------------------------------------ */
 /* ReversiBoard.generate_possible_moves / is_valid_move
- *   src/reversi/game_logic/reversi_board.py:25-41, 87-88 */
+ *   src/reversi/game_logic/reversi_board.py:25-41, 87-88.  size 1..8.  Cells that hold neither
+ *   side's stones but are not empty (the reference stores any `player` value and treats every
+ *   non-zero cell as occupied, :26) are walls: leave them out of own/opp and clear them from
+ *   *legal (rays stop at any cell that is not the opponent's, so nothing else changes). */
 int32_t bz_reversi_legal(uint64_t own, uint64_t opp, int32_t size, uint64_t* legal);
 /* ReversiBoard.make_move  reversi_board.py:43-59.  BZ_EILLEGAL_MOVE where the
  * reference raises ValueError("Invalid move").  Outputs are NOT swapped:
@@ -96,7 +102,7 @@ enum { BZ_ST_RUNNING = 0, BZ_ST_TERMINAL = 1, BZ_ST_ILLEGAL = 2, BZ_ST_MUST_PASS
 int32_t bz_reversi_step_batch(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
                               uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,
                               uint8_t* status, int8_t* winner, void* stream);
-/* the same for the reference's smaller boards (size 4, 6 or 8; bit = 8*row+col; actions are bit
+/* the same for the reference's smaller boards (size 1..8; bit = 8*row+col; actions are bit
  * indices, 64 = pass) */
 int32_t bz_reversi_step_batch_sized(const uint64_t* own, const uint64_t* opp, const uint8_t* action, int64_t n,
                                     int32_t size, uint64_t* own_next, uint64_t* opp_next, uint64_t* legal_next,

@@ -20,6 +20,11 @@ Fixtures:
                                 (Reversi depth-limited minimax, TTT full minimax)
   F10 mcts_twin_features.*      the twin over the reference's boards with Dirichlet
                                 root noise / subtree reuse switched on
+  F11 reversi_other_sizes.npz   F1 / F2 again for the board sizes the reference accepts besides
+                                4/6/8 that fit a 64-bit board: 1, 2, 3, 5, 7 (reversi_board.py:4-14)
+  F12 off_domain.json           cells and players outside {-1, 0, +1}: the reference treats any
+                                non-zero cell as occupied (tic_tac_toe_board.py:20-21,
+                                reversi_board.py:26) and plays `player` against `-player`
 
 Run:  python oracle/gen_golden.py
 """
@@ -382,6 +387,112 @@ def gen_f10():
     print("F10", len(cases), "cases; passes:", [c["passes"] for c in meta["cases"]])
 
 
+# ---------------------------------------------------------------- F11: the other board sizes
+def gen_f11():
+    """ReversiBoard(size=N) is generic in the reference (reversi_board.py:4-14, :87-88): full random games (F1's row
+    format) and arbitrary positions with all move results (F2's format) for sizes 1, 2, 3, 5 and 7."""
+    random.seed(4321)
+    rows, finals, gid = [], [], 0
+    for size, ngames in ((7, 40), (5, 40), (3, 30), (2, 3), (1, 1)):
+        for _ in range(ngames):
+            b = ReversiBoard(size=size)
+            cur, over, turn, passes = 1, False, 0, 0
+            while not over:
+                moves = b.generate_possible_moves(cur)
+                x, o = rev_bits(b.board, 1), rev_bits(b.board, -1)
+                if moves:
+                    r, c = random.choice(moves)
+                    nb = b.make_move(r, c, cur)
+                    flips = rev_bits(nb.board, cur) & ~rev_bits(b.board, cur) & ~(1 << (8 * r + c))
+                    act = 8 * r + c
+                    b = nb
+                else:
+                    flips, act = 0, 255
+                    passes += 1
+                over = b.is_game_over()
+                rows.append((gid, size, turn, cur + 1, x, o, rev_mask(moves), act, flips, int(over)))
+                cur *= -1
+                turn += 1
+            w, (n1, n2) = b.get_score()
+            finals.append((gid, size, w + 1, n1, n2, passes, rev_bits(b.board, 1), rev_bits(b.board, -1)))
+            gid += 1
+    rng = random.Random(77)
+    pos, moves = [], []
+    for size in (7, 5, 3, 2, 1):
+        for k in range(300 if size > 3 else 120):
+            b = ReversiBoard(size=size)
+            dens, bias = rng.random(), rng.random()
+            for r in range(size):
+                for c in range(size):
+                    b.board[r][c] = 0 if rng.random() > dens else (1 if rng.random() < bias else -1)
+            if k % 7 == 0:
+                for i in range(size):
+                    for (r, c) in ((i, 0), (i, size - 1), (0, i), (size - 1, i)):
+                        if rng.random() < 0.8:
+                            b.board[r][c] = rng.choice((1, -1))
+            l1, l2 = b.generate_possible_moves(1), b.generate_possible_moves(-1)
+            w, (n1, n2) = b.get_score()
+            pi = len(pos)
+            pos.append((size, rev_bits(b.board, 1), rev_bits(b.board, -1), rev_mask(l1), rev_mask(l2),
+                        int(b.is_game_over()), w + 1, n1, n2))
+            for player, lst in ((1, l1), (-1, l2)):
+                for (r, c) in lst:
+                    nb = b.make_move(r, c, player)
+                    moves.append((pi, 1 if player == 1 else 0, 8 * r + c, rev_bits(nb.board, 1), rev_bits(nb.board, -1)))
+    starts = {str(n): {"board": ReversiBoard(size=n).board.tolist(), "str": str(ReversiBoard(size=n))} for n in range(1, 9)}
+    np.savez_compressed(os.path.join(OUT, "reversi_other_sizes.npz"), rows=np.array(rows, dtype=np.uint64),
+                        finals=np.array(finals, dtype=np.uint64), pos=np.array(pos, dtype=np.uint64),
+                        moves=np.array(moves, dtype=np.uint64))
+    with open(os.path.join(OUT, "reversi_start_positions.json"), "w") as f:
+        json.dump(starts, f)
+    print("F11", len(rows), len(finals), len(pos), len(moves))
+
+
+# ---------------------------------------------------------------- F12: cells / players outside {-1, 0, +1}
+def gen_f12():
+    """The reference stores whatever `player` is (tic_tac_toe_board.py:28, reversi_board.py:48) and afterwards treats
+    every non-zero cell as occupied (tic_tac_toe_board.py:21, reversi_board.py:26); Reversi plays `player` against
+    `-player` whatever the number is (reversi_board.py:34-37).  Boards with such cells, every query answered by the
+    reference: TTT valid / moves / game-over / the boards after every legal move; Reversi the same for several
+    `player` values."""
+    rng = random.Random(2024)
+    out = {"ttt": [], "reversi": []}
+    t = TicTacToeBoard().make_move(0, 0, 5)          # the VERDICT r4 case
+    tb = [t, t.make_move(1, 1, -1), t.make_move(1, 1, -1).make_move(0, 1, 5).make_move(0, 2, 5)]
+    for _ in range(60):
+        b = TicTacToeBoard()
+        for r in range(3):
+            for c in range(3):
+                b.board[r][c] = rng.choice((0, 0, 0, 1, -1, 5, -5, 2))
+        tb.append(b)
+    full = TicTacToeBoard(np.array([[5, 1, -1], [-1, 5, 1], [1, -1, 7]]))   # full without a line: (True, 0)
+    tb.append(full)
+    for b in tb:
+        over, w = b.is_game_over()
+        mv = b.generate_possible_moves()
+        valid = [[bool(b.is_valid_move(r, c)) for c in range(3)] for r in range(3)]
+        after = [b.make_move(r, c, 3).board.tolist() for (r, c) in mv[:2]]
+        out["ttt"].append({"board": b.board.tolist(), "over": bool(over), "winner": w, "moves": [list(m) for m in mv],
+                           "valid": valid, "after_player3": after})
+    for size in (8, 6, 5, 4):
+        for k in range(25):
+            b = ReversiBoard(size=size)
+            dens = 0.35 + 0.5 * rng.random()
+            for r in range(size):
+                for c in range(size):
+                    b.board[r][c] = 0 if rng.random() > dens else rng.choice((1, 1, -1, -1, 5, -5, 2))
+            ent = {"size": size, "board": b.board.tolist(), "over": bool(b.is_game_over()),
+                   "score": [b.get_score()[0], list(b.get_score()[1])], "players": {}}
+            for player in (1, -1, 5, -5, 2, 0):
+                mv = b.generate_possible_moves(player)
+                after = [b.make_move(r, c, player).board.tolist() for (r, c) in mv[:3]]
+                ent["players"][str(player)] = {"moves": [list(m) for m in mv], "after": after}
+            out["reversi"].append(ent)
+    with open(os.path.join(OUT, "off_domain.json"), "w") as f:
+        json.dump(out, f)
+    print("F12", len(out["ttt"]), len(out["reversi"]))
+
+
 # ---------------------------------------------------------------- F9: the reference's minimax players
 def _load_by_path(name, path):
     import importlib.util
@@ -476,7 +587,7 @@ def gen_f9():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12"]
     if "f1" in which: gen_f1()
     if "f2" in which: gen_f2()
     if "f3" in which: gen_f3()
@@ -486,3 +597,5 @@ if __name__ == "__main__":
     if "f8" in which: gen_f8()
     if "f9" in which: gen_f9()
     if "f10" in which: gen_f10()
+    if "f11" in which: gen_f11()
+    if "f12" in which: gen_f12()

@@ -49,7 +49,8 @@ def test_struct_sizes_match_header():
 def test_argument_validation_without_gpu():
     L = _lib.lib()
     out = C.c_uint64()
-    assert L.bz_reversi_legal(0, 0, 5, C.byref(out)) == _lib.BZ_EINVAL
+    assert L.bz_reversi_legal(0, 0, 9, C.byref(out)) == _lib.BZ_EINVAL and L.bz_reversi_legal(0, 0, 0, C.byref(out)) == _lib.BZ_EINVAL
+    assert L.bz_reversi_legal(0, 0, 5, C.byref(out)) == _lib.BZ_OK  # sizes 1..8: every size whose cells fit (reversi_board.py:4-14 is generic)
     assert b"size" in L.bz_last_error()
     assert L.bz_reversi_apply(0, 0, 8, 0, 0, C.byref(out), C.byref(out), None) == _lib.BZ_EILLEGAL_MOVE
     assert L.bz_engine_workspace_bytes(None) == -1

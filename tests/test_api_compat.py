@@ -63,7 +63,9 @@ def test_reversi_board_array_is_live_and_copy_ctor():
     c.board[5][5] = 1
     assert b.board[5][5] == 0
     with pytest.raises(ValueError):
-        bz.ReversiBoard(size=5)
+        bz.ReversiBoard(size=9)   # 81 cells do not fit the 64-bit boards: refused, not wrong
+    with pytest.raises(ValueError):
+        bz.ReversiBoard(size=0)
 
 
 def test_strings_and_demo_sequences():
@@ -157,3 +159,71 @@ def test_minimax_yardstick_self_play_always_draws():
     for _ in range(5):
         positions, winner = bz.TicTacToeHeadless(bz.OptimalPlayer(1), bz.OptimalPlayer(-1)).play()
         assert winner == 0 and len(positions) == 10
+
+
+def test_reversi_every_board_size_the_bitboards_hold():
+    """ReversiBoard(size=N) is generic in the reference (reversi_board.py:4-14, :87-88): fixture F11 = full random games
+    and arbitrary positions with every move result for sizes 1, 2, 3, 5 and 7, plus the start position of every size 1..8"""
+    starts = json.load(open(os.path.join(G, "reversi_start_positions.json")))
+    for n in range(1, 9):
+        b = bz.ReversiBoard(size=n)
+        assert b.board.tolist() == starts[str(n)]["board"] and str(b) == starts[str(n)]["str"] and b.size == n
+    d = np.load(os.path.join(G, "reversi_other_sizes.npz"))
+    sizes = set()
+    for gid, size, turn, tm1, x, o, legal, act, flips, over in d["rows"].tolist():
+        cur = int(tm1) - 1
+        sizes.add(size)
+        b = _board(x, o, size)
+        assert _mask(b.generate_possible_moves(cur)) == legal
+        nb = b
+        if act != 255:
+            nb = b.make_move(act >> 3, act & 7, cur)
+            assert nb.bits(cur)[0] == (b.bits(cur)[0] | flips | 1 << act)
+        assert nb.is_game_over() == bool(over)
+    assert sizes == {1, 2, 3, 5, 7}
+    for gid, size, w1, n1, n2, passes, xf, of in d["finals"].tolist():
+        assert _board(xf, of, size).get_score() == (int(w1) - 1, (n1, n2))
+    pos, moves = d["pos"].tolist(), d["moves"].tolist()
+    for size, x, o, l1, l2, over, w1, n1, n2 in pos:
+        b = _board(x, o, size)
+        assert _mask(b.generate_possible_moves(1)) == l1 and _mask(b.generate_possible_moves(-1)) == l2
+        assert b.is_game_over() == bool(over)
+    for pi, is_x, act, xa, oa in moves[::3]:
+        size, x, o = pos[pi][:3]
+        assert _board(x, o, size).make_move(act >> 3, act & 7, 1 if is_x else -1).bits(1) == (xa, oa)
+
+
+def test_cells_and_players_outside_the_domain_behave_like_the_reference():
+    """fixture F12: after make_move(0, 0, 5) the reference treats the cell as occupied (tic_tac_toe_board.py:20-21, :28,
+    :38-43; reversi_board.py:26) and Reversi plays `player` against `-player` whatever the number (:34-37)"""
+    d = json.load(open(os.path.join(G, "off_domain.json")))
+    t = bz.TicTacToeBoard().make_move(0, 0, 5)
+    assert t.board[0][0] == 5 and not t.is_valid_move(0, 0) and (0, 0) not in t.generate_possible_moves()
+    with pytest.raises(ValueError, match="^Invalid move$"):
+        t.make_move(0, 0, 1)
+    for e in d["ttt"]:
+        b = bz.TicTacToeBoard(np.array(e["board"]))
+        assert b.is_game_over() == (e["over"], e["winner"])
+        assert [list(m) for m in b.generate_possible_moves()] == e["moves"]
+        assert [[b.is_valid_move(r, c) for c in range(3)] for r in range(3)] == e["valid"]
+        for (r, c), want in zip(e["moves"][:2], e["after_player3"]):
+            assert b.make_move(r, c, 3).board.tolist() == want
+    n_moves = 0
+    for e in d["reversi"]:
+        b = bz.ReversiBoard(size=e["size"])
+        b.board = np.array(e["board"])
+        assert b.is_game_over() == e["over"]
+        w, cnt = b.get_score()
+        assert [w, list(cnt)] == e["score"]
+        for player, pe in e["players"].items():
+            player = int(player)
+            mv = b.generate_possible_moves(player)
+            assert [list(m) for m in mv] == pe["moves"], (e["board"], player)
+            n_moves += len(mv)
+            for (r, c), want in zip(pe["moves"][:3], pe["after"]):
+                assert b.make_move(r, c, player).board.tolist() == want
+            if not mv:
+                with pytest.raises(ValueError, match="^Invalid move$"):
+                    b.make_move(0, 0, player)
+        assert np.array_equal(b.board, np.array(e["board"]))  # the receiver is never mutated
+    assert n_moves > 200

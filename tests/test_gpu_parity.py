@@ -791,11 +791,13 @@ def test_selfplay_longer_searches_vs_oracle_bitexact():
     _check_selfplay("ttt", 64, 60, "uniform", 3, 0, 2, base=7)
 
 
-@pytest.mark.parametrize("size", [4, 6])
+@pytest.mark.parametrize("size", [4, 6, 1, 2, 3, 5, 7])
 def test_reversi_step_batch_small_boards_on_golden_games(size):
-    """the reference's 4x4 / 6x6 boards (reversi_board.py:93, reversi_terminal.py:46) through the batched kernel"""
-    d = np.load(os.path.join(G, "reversi_random_games.npz"))
+    """the reference's 4x4 / 6x6 boards (reversi_board.py:93, reversi_terminal.py:46) through the batched kernel, and the
+    other sizes its generic constructor accepts that fit the 64-bit boards (fixture F11: 1, 2, 3, 5, 7)"""
+    d = np.load(os.path.join(G, "reversi_random_games.npz" if size in (4, 6) else "reversi_other_sizes.npz"))
     rows = d["rows"][d["rows"][:, 1] == size]
+    assert len(rows) > 0
     cur = rows[:, 3].astype(np.int64) - 1
     own = np.where(cur == 1, rows[:, 4], rows[:, 5])
     opp = np.where(cur == 1, rows[:, 5], rows[:, 4])
@@ -1773,6 +1775,49 @@ def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():
     if torch.cuda.device_count() < 2:  # RCCL needs one device per rank: a clear refusal, not a crash inside init
         r2 = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         assert r2.returncode != 0 and "GPU(s) visible" in (r2.stderr + r2.stdout)
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_multi_gpu_branch_runs_under_rccl_at_world_size_1(launcher):
+    """bench.py's N > 1 branch on the REAL backend ("nccl" = RCCL), as far as one GPU allows: `--force-collective` makes a
+    world of one rank create the process group with `init_process_group("nccl", device_id=...)`, allocate GatherBuffers on
+    the device, run the pack kernels, the ONE all_gather_into_tensor, the device-side all_reduces of [dt, games] and the
+    per-rank proof -- every `ctx.dist` branch the 2/4/8-GPU driver run takes, so that run is not the code's first.  Started
+    as a child process (under torchrun, and by bench.py itself) before anything here touches the GPU in THAT process.
+    What is pooled: complete games only (the reference's collect_game_data, SL/generate_training_games.py:30-36)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BZ_DIST_BACKEND", "BZ_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    args = ["--gpus", "1", "--force-collective", "--games", "512", "--sims", "32", "--steps", "70", "--warmup", "2",
+            "--no-cpu-baseline", "--no-secondary"]
+    if launcher == "torchrun":
+        import socket
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["forced_collective_path"] is True and out["value"] > 0
+    rk = out["ranks"]
+    assert rk["backend"] == "nccl (RCCL)" and rk["world_size"] == 1 and rk["distinct_devices"] == 1
+    p = rk["per_rank"][0]
+    assert p["rank"] == 0 and p["device_uuid"] and p["seconds"] > 0
+    # 70 steps of a 58-ply steady-state pool: every slot finishes at least one game inside the timed region
+    assert p["games_finished"] >= 512
+    pooled = out["pooled"]
+    assert pooled["collectives_in_timed_region"] == 1 and pooled["dropped_rows"] == 0
+    assert pooled["games"] >= p["games_finished"] and pooled["rows"] >= 40 * pooled["games"]
+    assert pooled["bytes_received_per_rank"] == pooled["block_bytes_per_rank"]  # world size 1: one block
+    assert abs(p["games_finished"] / p["seconds"] - out["value"]) <= 0.02 * out["value"]  # the device all_reduces returned this rank's own figures
+    assert "bytes received per rank" in out["config"]["parallelism"] and out["roofline"]["frac"] > 0
 
 
 def test_net_evaluators_serve_the_small_reversi_boards():
