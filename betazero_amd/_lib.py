@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # BZ_HIP_SO: load a diagnostic variant built by betazero_amd.build.build_variant() instead of the
 # product library (needs BZ_ALLOW_EXPERIMENT=1 as well: such builds may time but not compute)
 SO = os.environ.get("BZ_HIP_SO") or os.path.join(HERE, "libbz_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 BZ_OK, BZ_EINVAL, BZ_EILLEGAL_MOVE, BZ_EHIP, BZ_ENOMEM, BZ_ENOGPU, BZ_ESTATE = range(7)
 GAME_TTT, GAME_REVERSI, GAME_REVERSI6, GAME_REVERSI4 = 0, 1, 2, 3

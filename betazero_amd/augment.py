@@ -19,8 +19,11 @@ def _first_occurrences(key8, own8, opp8, pi8):
     of its group on the full content: the head is kept, rows equal to it are duplicates and dropped, rows that differ
     (another content sharing the key) go into the next pass among themselves -- so the result is exact whatever the
     keys do: a collision can neither drop a distinct row nor keep a duplicate.  With honest keys that is one pass plus
-    one emptiness check."""
+    one emptiness check.  pi is compared by BIT PATTERN (a row holding a NaN equals itself -- with float comparison a
+    group head containing a NaN differed from itself and was handed to the next pass for ever), and a pass never hands
+    its own heads on, so every pass removes at least one row: the loop ends."""
     kept = []
+    pi8 = pi8.view(torch.int32)
     cur = torch.arange(key8.numel(), device=key8.device)
     while cur.numel():
         sk, o = torch.sort(key8[cur], stable=True)
@@ -31,7 +34,7 @@ def _first_occurrences(key8, own8, opp8, pi8):
         head_row = order[heads[torch.cumsum(newrun, 0) - 1]]     # for every sorted position: the row id of its group's head
         same = (own8[order] == own8[head_row]) & (opp8[order] == opp8[head_row]) & (pi8[order] == pi8[head_row]).all(1)
         kept.append(order[newrun])
-        cur = torch.sort(order[~same]).values                    # ascending again: the stable sort keeps insertion order
+        cur = torch.sort(order[~same & ~newrun]).values          # ascending again: the stable sort keeps insertion order
     return torch.sort(torch.cat(kept)).values if kept else cur
 
 

@@ -14,6 +14,17 @@ inline int32_t hip_fail(hipError_t e, const char* what) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return BZ_EHIP;
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (kernel, DEVICE) pair: a process that runs the kernel on a second
+// GPU must set it there too.  `done` = one static word per call site, bit = device ordinal (devices >= 32: set every time).
+inline hipError_t lds_attr_per_device(const void* kernel, int bytes, unsigned* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 32 && ((*done >> dev) & 1u)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 32) *done |= 1u << dev;
+    return e;
+}
 // kernel timers (bz_env.hip); no-ops unless bz_profile_enable(1)
 int prof_begin(int slot, hipStream_t s);
 void prof_end(int slot, int idx, hipStream_t s);

@@ -599,10 +599,6 @@ __global__ void __launch_bounds__(Wg<C>::NT, 1) k_train_wgrad(WgradArgs T) {
 }
 
 bool train_shape_ok(int C, int L, int n) { return (C == 64 || C == 128) && L >= 2 && L % 2 == 0 && L <= 128 && n >= 1; }
-template <class G> int32_t set_lds(const void* k, int bytes) {
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return e == hipSuccess ? BZ_OK : hip_fail(e, "hipFuncSetAttribute(training kernel)");
-}
 }  // namespace
 
 BZ_EXPORT int64_t bz_train_wf_bytes(int32_t C, int32_t n_layers) {
@@ -651,8 +647,9 @@ static int32_t train_tower(bool bwd, const void* in, const void* wf, const float
     hipStream_t s = (hipStream_t)stream;
 #define BZ_TRAIN_LAUNCH(KERNEL, GEOM)                                                                              \
     do {                                                                                                           \
-        static bool once = false;                                                                                  \
-        if (!once) { int32_t rc = set_lds<GEOM>(reinterpret_cast<const void*>(KERNEL<GEOM>), GEOM::LDS); if (rc != BZ_OK) return rc; once = true; } \
+        static unsigned done = 0;   /* per (kernel, device) */                                                   \
+        if (hipError_t e_ = lds_attr_per_device(reinterpret_cast<const void*>(KERNEL<GEOM>), GEOM::LDS, &done); e_ != hipSuccess) \
+            return hip_fail(e_, "hipFuncSetAttribute(training kernel)");                                           \
         hipLaunchKernelGGL(KERNEL<GEOM>, dim3(n / GEOM::P), dim3(256), GEOM::LDS, s, T);                           \
     } while (0)
     // C = 64 keeps 8 positions per workgroup: n / 8 workgroups.  Below ~3/4 of the chip's 256 CUs, halve the tile instead
@@ -687,12 +684,12 @@ BZ_EXPORT int32_t bz_train_wgrad(const void* acts, const void* gs, int32_t C, in
     const int items = n_layers * splits, grid = ((items + 7) / 8) * 8 * (C / 64);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64) {
-        static bool once = false;
-        if (!once) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_wgrad<64>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg<64>::LDS); if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_wgrad)"); once = true; }
+        static unsigned done = 0;
+        if (hipError_t e = lds_attr_per_device(reinterpret_cast<const void*>(k_train_wgrad<64>), Wg<64>::LDS, &done); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_wgrad)");
         hipLaunchKernelGGL(k_train_wgrad<64>, dim3(grid), dim3(Wg<64>::NT), Wg<64>::LDS, s, T);
     } else {
-        static bool once = false;
-        if (!once) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_wgrad<128>), hipFuncAttributeMaxDynamicSharedMemorySize, Wg<128>::LDS); if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_wgrad)"); once = true; }
+        static unsigned done = 0;
+        if (hipError_t e = lds_attr_per_device(reinterpret_cast<const void*>(k_train_wgrad<128>), Wg<128>::LDS, &done); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_wgrad)");
         hipLaunchKernelGGL(k_train_wgrad<128>, dim3(grid), dim3(Wg<128>::NT), Wg<128>::LDS, s, T);
     }
     BZ_LAUNCH_CHECK("k_train_wgrad");

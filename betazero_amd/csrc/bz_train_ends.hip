@@ -61,10 +61,18 @@ __device__ __forceinline__ unsigned nbhd_bits(unsigned long long own, unsigned l
 // the batch of a step: a descriptor in DEVICE memory (bz_train_batch, bz_abi.h) read at launch time, so that a captured
 // graph keeps working when the data set's tensors are replaced (the host rewrites 48 bytes).  Row of batch position p:
 // idx[p] clamped into the data set (an index out of range must not become a fault), or p itself without an index.
+// A clamped index is an ERROR of the caller, not a feature: k_train_heads counts the batch positions whose index was out
+// of range (batch_row_bad) into the step's error word, losses[3] (bz_train_finish), which the host checks when it reads
+// the losses -- the step trained on row 0 / n_rows - 1 in that position's place.
+__device__ __forceinline__ long long batch_row_raw(const bz_train_batch& B, int p) { return B.idx ? B.idx[p] : (long long)p; }
 __device__ __forceinline__ long long batch_row(const bz_train_batch& B, int p) {
-    long long r = B.idx ? B.idx[p] : (long long)p;
+    long long r = batch_row_raw(B, p);
     r = r < 0 ? 0 : r;
-    return r < B.n_rows ? r : B.n_rows - 1;
+    return r < B.n_rows ? r : (B.n_rows > 0 ? B.n_rows - 1 : 0);
+}
+__device__ __forceinline__ bool batch_row_bad(const bz_train_batch& B, int p) {
+    const long long r = batch_row_raw(B, p);
+    return r < 0 || r >= B.n_rows;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -197,17 +205,17 @@ struct HeadArgs {
     const float *pol_w, *pol_b, *polfc_w, *polfc_b, *val_w, *val_b, *v1_w, *v1_b, *v2_w, *v2_b;
     __bf16* g_top;            // [n][64][C]
     float *hv, *dl, *dv1;     // [n][192], [n][65], [n][64]
-    float* partial;           // [gridDim.x][3 C + 200]
+    float* partial;           // [gridDim.x][3 C + 201]
 };
 // the partial vector: [0, 3C) d hw (pol.weight [2][C], then val.weight [C]) | 3: d hb | 65: d polfc.bias | 64: d v1.bias |
-// 64: d v2.weight | 1: d v2.bias | 3: loss, CE, MSE
+// 64: d v2.weight | 1: d v2.bias | 3: loss, CE, MSE | 1: batch positions whose row index was out of range (the error word)
 template <int C> struct Hd {
     static constexpr int XS = C + 8;                         // bf16 per LDS row of x (16 bytes of padding: conflict-free 16-byte reads down a column)
     static constexpr int WT = 0, V1T = 128 * 65, HWS = V1T + 64 * 65, SHARED = HWS + 3 * C;   // floats
     static constexpr int W_X = 0, W_HV = 64 * XS / 2, W_DP = W_HV + 192, W_DL = W_DP + 256, W_DV1 = W_DL + 68, W_FLOATS = W_DV1 + 64;
     static constexpr int LDS = (SHARED + 4 * W_FLOATS) * 4;
     static constexpr int O_HB = 3 * C, O_PFB = O_HB + 3, O_V1B = O_PFB + 65, O_V2W = O_V1B + 64, O_V2B = O_V2W + 64, O_LOSS = O_V2B + 1,
-                         NP = O_LOSS + 3;
+                         NP = O_LOSS + 4;
 };
 
 template <int C>
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
     const float v1b = lane < A.VH ? A.v1_b[lane] : 0.0f, v2w = lane < A.VH ? A.v2_w[lane] : 0.0f;
 
     float acc_hw[3][CPL], acc_hb[3] = {0.0f, 0.0f, 0.0f}, acc_pfb = 0.0f, acc_pfb64 = 0.0f, acc_v1b = 0.0f, acc_v2w = 0.0f, acc_v2b = 0.0f,
-          acc_ce = 0.0f, acc_mse = 0.0f;
+          acc_ce = 0.0f, acc_mse = 0.0f, acc_bad = 0.0f;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
     for (int grp = blockIdx.x; grp * 4 < A.n; grp += gridDim.x) {   // (n is a multiple of 4: every wave of a pass has a position)
         const int pos = grp * 4 + wv;
         const long long row = batch_row(B, pos);
+        acc_bad += batch_row_bad(B, pos) ? 1.0f : 0.0f;
         // (the targets are needed in steps B and C: asked for now, they arrive under step A)
         const float pa = B.pi[(size_t)row * 65 + lane], p64 = B.pi[(size_t)row * 65 + 64], zf = (float)B.z[row];
         __syncthreads();   // the previous pass's copy-out has read xs; (first pass: the weight tables are in place)
@@ -397,6 +406,7 @@ __global__ __launch_bounds__(256) void k_train_heads(HeadArgs A) {
         red[H::O_PFB + 64] = acc_pfb64;
         red[H::O_V2B] = acc_v2b;
         red[H::O_LOSS] = acc_ce + acc_mse; red[H::O_LOSS + 1] = acc_ce; red[H::O_LOSS + 2] = acc_mse;
+        red[H::O_LOSS + 3] = acc_bad;   // (wave-uniform: one position per wave and pass)
     }
     __syncthreads();
     for (int o = tid; o < H::NP; o += 256)
@@ -453,6 +463,7 @@ struct ReduceJob {
     float* dst;
     int count, parts, stride, inner, outer_stride;   // o = hi * inner + lo  ->  src[hi * outer_stride + s * stride + lo]
     int block0;
+    int sticky_from;   // outputs o >= sticky_from are ADDED to dst instead of stored (the step's error word); INT_MAX: none
 };
 // Adam (Kingma & Ba; torch.optim.Adam's arithmetic, no weight decay / amsgrad -- what train.py:87 constructs) on one element
 struct AdamScalars { float lr, beta1, beta2, eps, bc1, bc2_rsqrt; };   // bc1 = 1 - beta1^t, bc2_rsqrt = 1 / sqrt(1 - beta2^t)
@@ -518,7 +529,10 @@ __global__ __launch_bounds__(256) void k_train_finish(FinishArgs F) {
     }
     vals[tid] = sum;
     __syncthreads();
-    if (tid < 64 && o < J.count) J.dst[o] = (vals[tid] + vals[tid + 64]) + (vals[tid + 128] + vals[tid + 192]);
+    if (tid < 64 && o < J.count) {
+        const float v = (vals[tid] + vals[tid + 64]) + (vals[tid + 128] + vals[tid + 192]);
+        J.dst[o] = o >= J.sticky_from ? J.dst[o] + v : v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -564,7 +578,7 @@ int heads_w_blocks(int n) { const int g = (n + 7) / 8; return g < 128 ? g : 128;
 BZ_EXPORT int32_t bz_train_ends_sizes(int32_t C, int32_t n, int32_t* sizes) {
     BZ_REQUIRE(sizes && ends_shape_ok(C, n), "bz_train_ends_sizes: C must be 64 or 128 and the batch a multiple of 4");
     sizes[0] = stem_blocks(n); sizes[1] = C * 19;
-    sizes[2] = heads_blocks(n); sizes[3] = 3 * C + 200;
+    sizes[2] = heads_blocks(n); sizes[3] = 3 * C + 201;
     sizes[4] = heads_w_blocks(n); sizes[5] = kHeadWOut;
     return BZ_OK;
 }
@@ -606,12 +620,12 @@ BZ_EXPORT int32_t bz_train_heads(const void* act_top, const bz_train_batch* batc
     const dim3 grid(heads_blocks(n));
     hipStream_t s = (hipStream_t)stream;
     if (C == 64) {
-        static bool once = false;
-        if (!once) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_heads<64>), hipFuncAttributeMaxDynamicSharedMemorySize, Hd<64>::LDS); if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_heads)"); once = true; }
+        static unsigned done = 0;
+        if (hipError_t e = lds_attr_per_device(reinterpret_cast<const void*>(k_train_heads<64>), Hd<64>::LDS, &done); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_heads)");
         hipLaunchKernelGGL(k_train_heads<64>, grid, dim3(256), Hd<64>::LDS, s, A);
     } else {
-        static bool once = false;
-        if (!once) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_heads<128>), hipFuncAttributeMaxDynamicSharedMemorySize, Hd<128>::LDS); if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_heads)"); once = true; }
+        static unsigned done = 0;
+        if (hipError_t e = lds_attr_per_device(reinterpret_cast<const void*>(k_train_heads<128>), Hd<128>::LDS, &done); e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_train_heads)");
         hipLaunchKernelGGL(k_train_heads<128>, grid, dim3(256), Hd<128>::LDS, s, A);
     }
     BZ_LAUNCH_CHECK("k_train_heads");
@@ -653,10 +667,11 @@ BZ_EXPORT int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_ten
         ReduceJob& J = F.job[F.n_jobs++];
         J.src = src; J.dst = field ? G->*field : dst_plain;
         J.count = count; J.parts = parts; J.stride = stride; J.inner = inner; J.outer_stride = outer_stride; J.block0 = next_block;
+        J.sticky_from = 0x7fffffff;
         next_block += (count + 63) / 64;
     };
     typedef bz_train_tensors T;
-    const int nS = stem_blocks(n), nH = heads_blocks(n), nW = heads_w_blocks(n), NP = 3 * C + 200;
+    const int nS = stem_blocks(n), nH = heads_blocks(n), nW = heads_w_blocks(n), NP = 3 * C + 201;
     const int bias_rows = 2 * Q->splits * (C / 32);   // bz_train_wgrad_bias_rows()
     add(Q->tower_b, &T::tower_b, nullptr, n_layers * C, bias_rows, C, C, bias_rows * C);
     add(Q->stem, &T::stem_w, nullptr, C * 18, nS, C * 19, C * 18, 0);
@@ -669,7 +684,8 @@ BZ_EXPORT int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_ten
     add(Q->heads + 3 * C + 68, &T::v1_b, nullptr, VH, nH, NP, VH, 0);
     add(Q->heads + 3 * C + 132, &T::v2_w, nullptr, VH, nH, NP, VH, 0);
     add(Q->heads + 3 * C + 196, &T::v2_b, nullptr, 1, nH, NP, 1, 0);
-    add(Q->heads + 3 * C + 197, nullptr, losses, 3, nH, NP, 3, 0);
+    add(Q->heads + 3 * C + 197, nullptr, losses, 4, nH, NP, 4, 0);
+    F.job[F.n_jobs - 1].sticky_from = 3;   // losses[3], the error word, ACCUMULATES until the caller zeroes it
     add(Q->heads_w, &T::polfc_w, nullptr, 65 * 128, nW, kHeadWOut, 65 * 128, 0);
     add(Q->heads_w + 65 * 128, &T::v1_w, nullptr, VH * 64, nW, kHeadWOut, VH * 64, 0);
     hipLaunchKernelGGL(k_train_finish, dim3(n_layers * C + next_block), dim3(256), 0, (hipStream_t)stream, F);

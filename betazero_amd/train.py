@@ -58,18 +58,57 @@ def train_step(module, optimizer, ex, idx=None, device="cuda:0", autocast=True):
     return loss.detach(), ce.detach(), mse.detach()
 
 
+def holdout_split(n_rows, val_fraction=0.2, generator=None, device="cuda:0"):
+    """the reference's train / validation split (SL/train.py:66-76: val_size = int(total_size * validation_split), a
+    random split of the ROWS) as two device index tensors (train_idx, val_idx) into a data set of n_rows rows"""
+    perm = torch.randperm(int(n_rows), generator=generator, device=device)
+    n_val = int(int(n_rows) * val_fraction)
+    return perm[n_val:], perm[:n_val]
+
+
+def select_rows(ex, idx):
+    """DeviceExamples holding the rows `idx` (a device index tensor) of ex"""
+    return DeviceExamples(own=ex.own[idx], opp=ex.opp[idx], pi=ex.pi[idx], z=ex.z[idx], mover=ex.mover[idx], act=ex.act[idx],
+                          game=ex.game[idx], ply=ex.ply[idx], size=ex.size)
+
+
+@torch.no_grad()
+def validate(device_net, ex, idx=None):
+    """The validation line of the reference's training loop (SL/train.py:121-146: loss and accuracy on the held-out rows
+    after every epoch) for (s, pi, z) examples, on the net the SEARCH uses -- the engine's bf16 MFMA forward
+    (DeviceNet.forward), i.e. on the weights as they will play: mean policy cross-entropy against pi, value MSE against z,
+    and top-1 agreement (argmax of the logits == argmax of pi; the reference's accuracy is `predicted == actions.argmax`,
+    :139-142).  Everything stays on the GPU; returns a dict of Python floats (one synchronisation)."""
+    own, opp, pi, z = (ex.own, ex.opp, ex.pi, ex.z) if idx is None else (ex.own[idx], ex.opp[idx], ex.pi[idx], ex.z[idx])
+    n = int(own.shape[0])
+    if n == 0:
+        return {"rows": 0, "policy_ce": None, "value_mse": None, "top1": None}
+    ce = torch.zeros((), dtype=torch.float64, device=own.device)
+    se, hit = torch.zeros_like(ce), torch.zeros_like(ce)
+    for a in range(0, n, device_net.max_batch):
+        b = min(n, a + device_net.max_batch)
+        logits, v = device_net.forward(own[a:b].contiguous(), opp[a:b].contiguous())
+        ce += -(pi[a:b] * F.log_softmax(logits, dim=1)).sum()
+        se += ((v - z[a:b].to(torch.float32)) ** 2).sum()
+        hit += (logits.argmax(1) == pi[a:b].argmax(1)).sum()
+    ce, se, hit = (float(t) / n for t in (ce, se, hit))
+    return {"rows": n, "loss": ce + se, "policy_ce": ce, "value_mse": se, "top1": hit}
+
+
 class GraphedTrainStep:
-    """train_step() captured ONCE into a HIP graph and replayed: a step of a small net is ~150 short kernels (casts,
-    convolutions, point-wise ops, the optimiser), i.e. launch-bound in eager mode; the replay issues them back to back.
-    Same arithmetic as train_step (same module, Adam, bf16 autocast), fixed batch size.
+    """train_step() with every buffer static and, for the all-kernel step, captured ONCE into a HIP graph and replayed (ten
+    launches back to back instead of ten host calls).  Same arithmetic as train_step (same module, Adam, bf16 autocast),
+    fixed batch size.
 
         step = GraphedTrainStep(module, lr=2e-3, batch=1024, na=65)
         loss, ce, mse = step(examples, idx)      # idx: device index tensor of exactly `batch` rows
+        step.check()                             # where the losses are read: raises if an index was out of range
 
-    The optimiser lives inside (Adam with capturable=True: its step counter is a device tensor)."""
+    The optimiser lives inside (the Adam kernel, or torch's Adam with capturable=True: its step counter is a device tensor).
+    The forms of the step that go through torch autograd run eagerly unless capture_autograd=True (see __init__)."""
 
     def __init__(self, module, lr=1e-4, batch=1024, na=65, device="cuda:0", autocast=True, tower_kernels=None, lr_warmup_steps=0,
-                 step_kernels=None, fused_adam=None):
+                 step_kernels=None, fused_adam=None, capture_autograd=False):
         # (NCHW on purpose: channels-last convolutions measured ~20 % faster per step in tools/bench_train.py, but the
         # closed loop then failed to learn the value head in one run and produced non-finite weights in two others --
         # profiles/r03_az_loop_channels_last_failure.txt -- so that layout is not offered)
@@ -111,6 +150,13 @@ class GraphedTrainStep:
             self.optimizer = None
         else:
             self.optimizer = torch.optim.Adam(module.parameters(), lr=self.lr_t, capturable=True, fused=True)
+        # capture_autograd: a step that goes through torch autograd (step_kernels=False, or a module without the fused tower) is
+        # NOT captured into a HIP graph unless asked for -- it runs eagerly, same arithmetic.  Captured autograd steps returned
+        # wrong gradients once in a few hundred replays on this stack (a bias gradient of 6e32 at replay 305 / 306, an all-zero
+        # one at replay 702 / 703: profiles/r04_channels_last_cause.txt); the replay numbers repeat across seeds, so the cause
+        # is something deterministic that has not been found, and replacing the one reduction that was caught proves nothing
+        # about the others.  The all-kernel step (step_kernels) contains no torch kernel and is captured as before.
+        self.capture = self.step_plan is not None or bool(capture_autograd)
         self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.pi = torch.full((batch, na), 1.0 / na, dtype=torch.float32, device=self.dev)
@@ -174,13 +220,26 @@ class GraphedTrainStep:
             torch.index_select(ex.opp, 0, idx, out=self.opp)
             torch.index_select(ex.pi, 0, idx, out=self.pi)
             torch.index_select(ex.z, 0, idx, out=self.z)
+        if not self.capture:   # an autograd form of the step: eager (see capture_autograd in __init__)
+            self.module.train()
+            self.lr_t.fill_(self._lr_at(self.steps_done))
+            out = self._step()
+            self.steps_done += 1
+            return out[:3].clone()
         if self.graph is None:
             self._capture()
         if not self.fused_adam:
             self.lr_t.fill_(self._lr_at(self.steps_done))
         self.graph.replay()
         self.steps_done += 1
-        return self.out.clone()
+        return self.out[:3].clone()
+
+    def check(self):
+        """raise IndexError if a step since the last check was handed a row index outside the data set (the all-kernel step
+        clamps instead of faulting and counts the event in its error word; the autograd forms raise inside index_select).
+        Synchronises: call it where the losses are read, not every step."""
+        if self.step_plan is not None:
+            self.step_plan.check_rows()
 
 
 def refresh_device_net(device_net, module):

@@ -120,6 +120,9 @@ class _RowsLinear(torch.autograd.Function):
         # the bias gradient the same way (x a column of ones) rather than as gy.sum(0): a 65,536-row column sum is a
         # multi-block torch reduction, and inside replayed HIP graphs such sums came back wrong once in a few hundred
         # steps on this stack (all zeros here; 6e32 in the stock channels-last path -- profiles/r04_channels_last_cause.txt)
+        # (the CAUSE is unproven: the failing replay numbers repeat across seeds, which points at something deterministic in the
+        # captured reduction's buffers rather than at random flakiness -- DESIGN.md 9; so GraphedTrainStep no longer captures
+        # the autograd forms of the step at all unless asked to, train.py)
         gb = torch.bmm(gyc, gy.new_ones((ch, rows // ch, 1))).sum(0, dtype=torch.float32).squeeze(1)
         return gx, gW.to(ctx.dts[1]), gb.to(ctx.dts[2])
 
@@ -130,7 +133,7 @@ class StepPlan(TowerPlan):
 
         plan = StepPlan(module, batch)
         plan.set_batch(own, opp, pi, z, idx)     # the data set's tensors and the batch's row indices (idx None: rows 0..batch-1)
-        losses = plan.grads()                    # [loss, policy CE, value MSE] (device, static); every p.grad is set
+        losses = plan.grads()                    # [loss, policy CE, value MSE, error word] (device, static); every p.grad is set
         optimizer.step()                         # torch's -- or instead of the two lines above:
         plan.enable_adam(lr); losses = plan.step()    # + the Adam update as a tenth launch (torch.optim.Adam's arithmetic)
 
@@ -164,7 +167,7 @@ class StepPlan(TowerPlan):
         f32 = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
         self.stem_partial, self.heads_partial, self.heads_w_partial = f32(sizes[0], sizes[1]), f32(sizes[2], sizes[3]), f32(sizes[4], sizes[5])
         self.hv, self.dl, self.dv1 = f32(batch, 192), f32(batch, 65), f32(batch, 64)
-        self.losses = f32(3)
+        self.losses = f32(4)   # loss, CE, MSE and the error word: batch positions whose row index was out of range, summed over steps
         self._head = _lib.TrainHeadParams(**{k: named[k].data_ptr() for k, _ in _lib.TrainHeadParams._fields_})
         self._grads = _lib.TrainTensors(**{k: named[k].grad.data_ptr() for k in self.NAMES})
         self._partials = _lib.TrainPartials(tower=self.partial.data_ptr(), tower_b=self.db_partial.data_ptr(), stem=self.stem_partial.data_ptr(),
@@ -179,6 +182,8 @@ class StepPlan(TowerPlan):
         z).  Asynchronous on the current stream; the tensors are kept alive until the next call."""
         n, dev = self.n, self.device
         rows = int(own.shape[0])
+        if rows < 1:
+            raise ValueError("set_batch: the data set is empty")
         ok = (own.dtype == torch.int64 and opp.dtype == torch.int64 and own.shape == (rows,) and opp.shape == (rows,) and
               pi.dtype == torch.float32 and pi.shape == (rows, 65) and z.dtype == torch.int8 and z.shape == (rows,) and
               all(t.is_contiguous() and t.device == dev for t in (own, opp, pi, z)))
@@ -265,8 +270,25 @@ class StepPlan(TowerPlan):
                                   ct.byref(self._adam) if adam else None, st))
         return self.losses
 
+    def bad_rows(self, reset=True):
+        """the step's error word (bz_abi.h, bz_train_finish): how many batch positions since the last reset had a row index
+        outside the data set -- the kernels clamped them, i.e. trained on row 0 / the last row instead.  Reads the device
+        (synchronises); call it where the losses are looked at."""
+        n = int(self.losses[3].item())
+        if n and reset:
+            self.losses[3:4].zero_()
+        return n
+
+    def check_rows(self):
+        """raise IndexError if any step since the last check gathered a row outside the data set (what torch.index_select,
+        the loop shape of SL/train.py:102-108, would have raised at once)"""
+        n = self.bad_rows()
+        if n:
+            raise IndexError(f"StepPlan: {n} batch position(s) had a row index outside the data set since the last check; "
+                             "the kernels clamp instead of faulting, so those steps trained on the wrong rows")
+
     def grads(self, own=None, opp=None, pi=None, z=None, idx=None):
-        """forward, losses, backward: every parameter's .grad is set; returns the static [loss, CE, MSE] tensor.
+        """forward, losses, backward: every parameter's .grad is set; returns the static [loss, CE, MSE, error word] tensor.
         (own, opp, pi, z[, idx]) given: set_batch() first."""
         if own is not None:
             self.set_batch(own, opp, pi, z, idx)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BZ_ABI_VERSION 5
+#define BZ_ABI_VERSION 6
 
 enum { BZ_OK = 0, BZ_EINVAL = 1, BZ_EILLEGAL_MOVE = 2, BZ_EHIP = 3, BZ_ENOMEM = 4, BZ_ENOGPU = 5,
        BZ_ESTATE = 6 };
@@ -396,8 +396,10 @@ typedef struct bz_train_partials {      /* the partial sums the kernels of one s
 } bz_train_partials;
 /* The batch of a step.  This struct lives in DEVICE memory and is read by the kernels at launch time: a step captured
  * into a HIP graph keeps working when the data set's tensors are replaced or another batch is drawn -- the host rewrites
- * these 48 bytes (or just the idx array).  Batch position p is row idx[p] of the data set (clamped into [0, n_rows)), or
- * row p when idx is NULL.  The rows are what bz_engine_pack_examples / the example block hold: (s, pi, z) of
+ * these 48 bytes (or just the idx array).  Batch position p is row idx[p] of the data set, or row p when idx is NULL.  An
+ * index outside [0, n_rows) never becomes a fault -- the kernels read row 0 / n_rows - 1 in its place -- but it is an ERROR:
+ * every such batch position is counted into the step's error word, losses[3] of bz_train_finish (the reference's
+ * index_select-style gather, SL/train.py:102-108, raises on it).  The rows are what bz_engine_pack_examples / the example block hold: (s, pi, z) of
  * generate_training_games.py:12-23 in own/opp form. */
 typedef struct bz_train_batch {
     const uint64_t *own, *opp;          /* [n_rows] bitboards, side-to-move canonical */
@@ -431,7 +433,10 @@ int32_t bz_train_heads(const void* act_top, const bz_train_batch* batch_dev, int
                        const bz_train_head_params* P, void* g_top, float* hv, float* dl, float* dv1, float* partial, void* stream);
 /* partial [sizes[4]][sizes[5]] */
 int32_t bz_train_heads_wgrad(const float* hv, const float* dl, const float* dv1, int32_t n, int32_t VH, float* partial, void* stream);
-/* every partial sum -> the gradient tensors G (torch layouts); losses[3] = loss, policy CE, value MSE of the batch;
+/* every partial sum -> the gradient tensors G (torch layouts); losses[4] = loss, policy CE, value MSE of the batch, and the
+ * ERROR WORD: losses[3] += the number of batch positions of this step whose row index was out of range (bz_train_batch).
+ * The error word accumulates over steps (a graph can be replayed many times before the host looks): the caller zeroes it,
+ * and a value != 0 when the losses are read means some step trained on a wrong row.
  * opt != NULL: followed by the Adam update of every parameter (a second launch) */
 int32_t bz_train_finish(const bz_train_partials* Q, const bz_train_tensors* G, int32_t C, int32_t n_layers, int32_t VH, int32_t n,
                         float* losses, const bz_train_adam* opt, void* stream);

@@ -60,7 +60,7 @@ def test_argument_validation_without_gpu():
     sizes = (C.c_int32 * 6)()
     assert L.bz_train_ends_sizes(96, 64, sizes) == _lib.BZ_EINVAL and b"64 or 128" in L.bz_last_error()
     assert L.bz_train_ends_sizes(64, 6, sizes) == _lib.BZ_EINVAL                      # the batch must be a multiple of 4
-    assert L.bz_train_ends_sizes(128, 1024, sizes) == _lib.BZ_OK and list(sizes) == [512, 128 * 19, 256, 3 * 128 + 200, 128, 65 * 128 + 64 * 64]
+    assert L.bz_train_ends_sizes(128, 1024, sizes) == _lib.BZ_OK and list(sizes) == [512, 128 * 19, 256, 3 * 128 + 201, 128, 65 * 128 + 64 * 64]   # (heads: ... | loss, CE, MSE | the error word)
     assert L.bz_train_wgrad_bias_rows(128, 10) == 80 and L.bz_train_wgrad_bias_rows(96, 10) == 0
     assert L.bz_train_wf_bytes(96, 4) == -1 and L.bz_train_wf_bytes(128, 3) == -1      # width; odd number of conv layers
     assert L.bz_train_stem_fwd(None, 64, None, None, 64, None, None) == _lib.BZ_EINVAL

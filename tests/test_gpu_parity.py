@@ -487,6 +487,66 @@ def test_d4_augmentation_and_dedupe_match_the_reference_transforms():
         assert np.array_equal(f8.pi[t::8, :64], pi8[:, m]) and np.array_equal(f8.pi[t::8, 64], pi8[:, 64])
 
 
+def test_dedupe_terminates_on_nan_rows_and_keeps_first_occurrences():
+    """a pi row holding a NaN (a diverged net's targets) is not equal to itself under float comparison: the dedupe compares
+    bit patterns and never hands a group's head to the next pass, so it ends, keeps such a row once and drops its exact
+    copies like any other row"""
+    from betazero_amd.augment import augment_examples
+    from betazero_amd.engine import Examples
+    rng = np.random.default_rng(4)
+    n = 12
+    own = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64)
+    opp = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) & ~own
+    pi = rng.random((n, 65)).astype(np.float32)
+    pi[3, 10] = np.nan
+    own[7], opp[7], pi[7] = own[3], opp[3], pi[3]          # an exact copy of the NaN row
+    own[9], opp[9], pi[9] = own[2], opp[2], pi[2]          # and of an ordinary one
+    ex = Examples(own, opp, pi, np.zeros(n, np.int8), np.ones(n, np.int8), np.zeros(n, np.uint8), np.arange(n), np.zeros(n, np.int32), 8)
+    full = augment_examples(ex, dedupe=False)
+    out = augment_examples(ex, dedupe=True)
+    keys = [(int(a), int(b), p.tobytes()) for a, b, p in zip(full.own, full.opp, full.pi)]
+    first = [i for i, k in enumerate(keys) if k not in keys[:i]]
+    assert len(out) == len(first) < len(full)
+    assert np.array_equal(out.own, full.own[first]) and np.array_equal(out.pi.view(np.uint32), full.pi[first].view(np.uint32))
+    assert int(np.isnan(out.pi).any(1).sum()) == int(np.isnan(full.pi[first]).any(1).sum()) > 0
+
+
+def test_holdout_split_and_validation_line_on_the_engine_net():
+    """the reference's 80 / 20 split and per-epoch validation line (SL/train.py:66-78, :121-146) for (s, pi, z) rows:
+    holdout_split = a random partition with int(0.2 n) validation rows; validate() = policy CE, value MSE and top-1
+    agreement on the ENGINE's net (DeviceNet.forward, bf16 MFMA) against the same quantities from the torch module's
+    fp32 forward on the same rows (bf16 tolerance), and an index subset equals the selected rows"""
+    import torch.nn.functional as F
+    from betazero_amd.engine import DeviceExamples, Examples
+    from betazero_amd.net import DeviceNet
+    from betazero_amd.train import holdout_split, planes_from_bits, select_rows, validate
+    rng = np.random.default_rng(8)
+    n = 700
+    own, opp = _positions(n, seed=17)
+    pi = rng.random((n, 65)).astype(np.float32) ** 6
+    pi /= pi.sum(1, keepdims=True)
+    z = rng.integers(-1, 2, n).astype(np.int8)
+    ex = DeviceExamples.from_host(Examples(own, opp, pi, z, np.ones(n, np.int8), np.zeros(n, np.uint8), np.arange(n), np.zeros(n, np.int32), 8))
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    tr, va = holdout_split(n, 0.2, gen, DEV)
+    assert len(va) == int(n * 0.2) and len(tr) == n - len(va)
+    assert sorted(torch.cat([tr, va]).cpu().tolist()) == list(range(n))
+    m = _net(64, 2, bf16=True)
+    dn = DeviceNet.from_module(m, 256)                     # smaller than the validation set: validate() walks it in chunks
+    got = validate(dn, ex)
+    with torch.no_grad():
+        lg, v = m.cuda()(planes_from_bits(ex.own, ex.opp))
+    ce = float(-(ex.pi * F.log_softmax(lg.float(), dim=1)).sum(1).mean())
+    mse = float(((v.float() - ex.z.float()) ** 2).mean())
+    top1 = float((lg.argmax(1) == ex.pi.argmax(1)).float().mean())
+    assert got["rows"] == n and abs(got["policy_ce"] - ce) < 2e-3 and abs(got["value_mse"] - mse) < 2e-3
+    assert abs(got["top1"] - top1) <= 3 / n and abs(got["loss"] - (ce + mse)) < 4e-3
+    sub = validate(dn, ex, va)
+    sel = validate(dn, select_rows(ex, va))
+    assert sub == sel and sub["rows"] == len(va)
+    assert validate(dn, select_rows(ex, va[:0]))["policy_ce"] is None
+
+
 def test_device_resident_pipeline_gather_augment_train_never_visits_the_host(monkeypatch):
     """pack kernels -> all_gather_packed -> unpack -> augment_examples -> train_step up to loss.backward() with every
     device-to-host door bolted (Tensor.cpu / numpy / tolist / item raise; only a packed block's 256-byte header -- the

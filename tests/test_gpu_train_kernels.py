@@ -68,7 +68,9 @@ def test_tower_forward_and_saved_activations_vs_torch(C, L, n):
     assert torch.equal(y, plan.acts[L].float().view(n, 8, 8, C).permute(0, 3, 1, 2))
 
 
-@pytest.mark.parametrize("C,L,n", [(64, 4, 16), (128, 4, 32), (64, 8, 64), (128, 12, 64), (64, 4, 1536)])
+# ((128, 12, 1024) is the shape bench.py's `secondary.train_step` times: 12 conv layers x 128 channels x batch 1024 --
+# bz_train_wgrad_splits depends on the batch, so the timed shape is a tested shape)
+@pytest.mark.parametrize("C,L,n", [(64, 4, 16), (128, 4, 32), (64, 8, 64), (128, 12, 64), (64, 4, 1536), (128, 12, 1024)])
 def test_tower_gradients_vs_torch_autograd_fp32(C, L, n):
     """d/dx0, d/dW, d/db of sum(y * gy) through the kernels against torch.autograd over the fp32 reference tower (its
     layer outputs rounded to bf16 with a straight-through gradient, as the kernels store them).  The kernels keep
@@ -277,7 +279,7 @@ def test_heads_kernel_losses_and_gradients_vs_torch_fp32(C, n, VH):
     xr = x.float().requires_grad_(True)
     want = _heads_reference(m, xr, pi, z)
     want[0].backward()
-    assert np.allclose(losses.cpu().numpy(), [float(w) for w in want], rtol=2e-5, atol=1e-6), (losses, want)
+    assert np.allclose(losses[:3].cpu().numpy(), [float(w) for w in want], rtol=2e-5, atol=1e-6), (losses, want)
     for k in got:
         assert _rel(got[k], getattr(m, k).weight.grad) < 1e-4, (k, _rel(got[k], getattr(m, k).weight.grad))
         assert _rel(gotb[k], getattr(m, k).bias.grad) < 1e-4, (k, "bias")
@@ -286,7 +288,8 @@ def test_heads_kernel_losses_and_gradients_vs_torch_fp32(C, n, VH):
     assert float(g_top.abs().max()) > 0 and float((g_top != 0).float().mean()) > 0.05
 
 
-@pytest.mark.parametrize("C,NB,n", [(64, 2, 64), (128, 3, 32)])
+# ((128, 6, 1024) = the net and batch bench.py's `secondary.train_step` times)
+@pytest.mark.parametrize("C,NB,n", [(64, 2, 64), (128, 3, 32), (128, 6, 1024)])
 def test_whole_step_on_the_kernels_vs_torch_autograd_fp32(C, NB, n):
     """StepPlan.grads -- stem, tower, heads, losses and every gradient on the kernels -- against autograd through the
     plain fp32 torch forward of the same module (PolicyValueNet.forward without a plan) on the same batch: the losses
@@ -305,7 +308,8 @@ def test_whole_step_on_the_kernels_vs_torch_autograd_fp32(C, NB, n):
     mse = F.mse_loss(v, z.float())
     (ce + mse).backward()
     want = [float(ce + mse), float(ce), float(mse)]
-    assert np.allclose(losses.cpu().numpy(), want, rtol=2e-2, atol=2e-3), (losses, want)
+    assert np.allclose(losses[:3].cpu().numpy(), want, rtol=2e-2, atol=2e-3), (losses, want)
+    assert float(losses[3]) == 0.0   # the error word: no row index was out of range
     cos = {k: float(F.cosine_similarity(got[k].flatten(), p.grad.flatten(), dim=0)) for k, p in m.named_parameters() if p.numel() > 1}
     mag = {k: float(got[k].norm() / p.grad.norm().clamp(min=1e-20)) for k, p in m.named_parameters()}
     print("cosine of kernel vs autograd gradients:", {k: round(c, 4) for k, c in cos.items()})
@@ -319,10 +323,12 @@ def test_whole_step_on_the_kernels_vs_torch_autograd_fp32(C, NB, n):
         plan.grads(own, opp, pi, z)      # ... and StepPlan notices that its gradient tensors were swapped out
 
 
-def test_step_gathers_its_batch_rows_itself_and_clamps_bad_indices():
+def test_step_gathers_its_batch_rows_itself_and_flags_bad_indices():
     """the kernels read the batch through the device descriptor: rows idx of a larger data set give bit for bit the
-    losses and gradients of the same rows handed over contiguously; an index outside the data set is clamped to its
-    last / first row instead of faulting; pointing the plan at another data set changes nothing but the 48 bytes."""
+    losses and gradients of the same rows handed over contiguously; an index outside the data set does not fault (the
+    kernels read the last / first row in its place) but is an ERROR: the step's error word (losses[3], bz_abi.h) counts
+    every such batch position, stays set over later (clean) steps until it is read, and check_rows() raises IndexError;
+    pointing the plan at another data set changes nothing but the 48 bytes."""
     n, rows = 32, 304
     m, plan, own, opp, pi, z = _net_case(64, 1, rows, 24)
     from betazero_amd.train_kernels import StepPlan
@@ -333,17 +339,28 @@ def test_step_gathers_its_batch_rows_itself_and_clamps_bad_indices():
     ga = {k: p.grad.clone() for k, p in m.named_parameters()}
     b = plan.grads(own[idx].contiguous(), opp[idx].contiguous(), pi[idx].contiguous(), z[idx].contiguous()).clone()
     assert torch.equal(a, b) and all(torch.equal(ga[k], p.grad) for k, p in m.named_parameters())
+    assert float(a[3]) == 0.0 and plan.bad_rows() == 0
+    plan.check_rows()                                                 # nothing to complain about
     bad = idx.clone()
-    bad[3], bad[7] = rows + 1000, -5
+    bad[3], bad[7], bad[20] = rows + 1000, -5, rows                   # (rows itself is one past the end)
     good = idx.clone()
-    good[3], good[7] = rows - 1, 0
+    good[3], good[7], good[20] = rows - 1, 0, rows - 1
     c = plan.grads(own, opp, pi, z, bad).clone()
+    assert float(c[3]) == 3.0                                         # three batch positions were out of range
     d = plan.grads(own, opp, pi, z, good).clone()
-    assert torch.equal(c, d) and not torch.equal(c, a)
+    assert torch.equal(c[:3], d[:3]) and not torch.equal(c[:3], a[:3])   # clamped, not a fault ...
+    assert float(d[3]) == 3.0                                         # ... and the word is sticky over a clean step
+    c2 = plan.grads(own, opp, pi, z, bad).clone()
+    assert float(c2[3]) == 6.0                                        # it counts
+    with pytest.raises(IndexError, match="6 batch position"):
+        plan.check_rows()
+    assert plan.bad_rows() == 0                                       # reading resets it
+    a = a[:3]
     # another data set (new tensors, new addresses): only the descriptor changes -- a captured graph would keep working
     own2, opp2, pi2, z2 = (t.roll(7, 0).contiguous() for t in (own, opp, pi, z))
     e = plan.grads(own2, opp2, pi2, z2, idx).clone()
     f = plan.grads(own, opp, pi, z, (idx - 7) % rows).clone()      # the same rows of the original tensors
+    e, f = e[:3], f[:3]
     assert torch.equal(e, f) and not torch.equal(e, a)
     graph = torch.cuda.CUDAGraph()
     plan.set_batch(own, opp, pi, z, idx)
@@ -355,15 +372,21 @@ def test_step_gathers_its_batch_rows_itself_and_clamps_bad_indices():
     with torch.cuda.graph(graph):
         plan.launch()
     graph.replay()
-    assert torch.equal(plan.losses, a)
+    assert torch.equal(plan.losses[:3], a)
     plan.set_batch(own2, opp2, pi2, z2, idx)                       # ... and it does: same graph, other data set
     graph.replay()
     torch.cuda.synchronize()
-    assert torch.equal(plan.losses, e)
+    assert torch.equal(plan.losses[:3], e)
+    plan.set_batch(own, opp, pi, z, bad)                           # the captured step flags bad indices too
+    graph.replay()
+    graph.replay()
+    assert plan.bad_rows() == 6
     with pytest.raises(ValueError):
         plan.set_batch(own, opp, pi, z, idx[:8])              # not a whole batch of indices
     with pytest.raises(ValueError):
         plan.set_batch(own[:8], opp[:8], pi[:8], z[:8])       # fewer rows than the batch, no index
+    with pytest.raises(ValueError, match="empty"):
+        plan.set_batch(own[:0], opp[:0], pi[:0], z[:0], idx)  # an empty data set has no row to clamp to
 
 
 @pytest.mark.parametrize("warmup", [0, 4])

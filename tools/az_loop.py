@@ -2,9 +2,14 @@
 """The closed AlphaZero loop on one GPU, end to end through the package's public pieces:
 
     self-play (PipelinedSelfPlay: two engines on two streams, bf16 MFMA net in the loop, Dirichlet root noise, temperature moves)
-      -> example block -> 8-fold D4 augmentation + exact dedupe on the device (augment_examples)
-      -> policy cross-entropy + value MSE steps with stock PyTorch autograd under bf16 autocast (train_step)
+      -> example block -> 80 / 20 hold-out split of the new rows (the reference's split, SL/train.py:66-78)
+      -> 8-fold D4 augmentation + exact dedupe of the training part on the device (augment_examples)
+      -> policy cross-entropy + value MSE steps on the hand-written training kernels replayed as one HIP graph
+         (GraphedTrainStep: stem, tower, heads, losses, every gradient and Adam as ten launches; --miopen-train /
+         --eager-train / --fp32-train fall back to stock PyTorch autograd, run eagerly)
          -- the rows never leave the GPU between the engine's example block and the optimiser step
+      -> validation on the held-out rows with the engine's own bf16 MFMA forward (validate: policy CE, value MSE, top-1
+         agreement -- the reference's per-epoch validation line, SL/train.py:121-146)
       -> weights pushed back into the engine's net (refresh_device_net)
       -> batched arena against the reference's depth-limited minimax player (play_arena)
 
@@ -28,7 +33,8 @@ from betazero_amd.arena import play_arena  # noqa: E402
 from betazero_amd.augment import augment_examples  # noqa: E402
 from betazero_amd.engine import PipelinedSelfPlay, concat_device_examples  # noqa: E402
 from betazero_amd.net import DeviceNet, PolicyValueNet  # noqa: E402
-from betazero_amd.train import GraphedTrainStep, make_optimizer, refresh_device_net, train_step  # noqa: E402
+from betazero_amd.train import (GraphedTrainStep, holdout_split, make_optimizer, refresh_device_net, select_rows,  # noqa: E402
+                                train_step, validate)
 
 
 def main():
@@ -45,6 +51,8 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-3)
     ap.add_argument("--lr-warmup", type=int, default=300, help="steps over which the learning rate ramps up (GraphedTrainStep.lr_warmup_steps): "
                     "without it Adam's first steps at this lr can kill the head ReLUs -- profiles/r04_channels_last_cause.txt")
+    ap.add_argument("--val-split", type=float, default=0.2, help="fraction of every iteration's rows held out for validation "
+                    "(the reference's validation_split, SL/train.py:66); 0 = train on everything")
     ap.add_argument("--temp-moves", type=int, default=10)
     ap.add_argument("--arena-games", type=int, default=256)
     ap.add_argument("--arena-sims", type=int, default=64)
@@ -90,7 +98,7 @@ def main():
           **arena("uniform", None)})
     emit({"what": "arena, untrained net", "iter": 0, **arena("net_bf16", dnet)})
 
-    window = []
+    window, val_window = [], []
     for it in range(1, args.iters + 1):
         t0 = time.time()
         sp = PipelinedSelfPlay("reversi", args.games, args.sims, "net_bf16", dnet, pipelines=args.pipelines, temp_moves=args.temp_moves,
@@ -101,10 +109,14 @@ def main():
         torch.cuda.synchronize()
         t_play = time.time() - t0
         t1 = time.time()
-        aug = augment_examples(ex, dedupe=True)
+        # hold-out split of this iteration's rows BEFORE augmentation (a row's symmetric copies must not sit on both sides)
+        tr_idx, va_idx = holdout_split(len(ex), args.val_split, gen, ex.own.device)
+        aug = augment_examples(select_rows(ex, tr_idx), dedupe=True)
         del sp
         window = (window + [aug])[-args.window:]
-        data = concat_device_examples(window)
+        val_window = (val_window + [select_rows(ex, va_idx)])[-args.window:]
+        data, val = concat_device_examples(window), concat_device_examples(val_window)
+        val_before = validate(dnet, val)   # the net that just played, on rows it has not been trained on
         steps = max(1, int(args.epochs * len(data) / args.batch))
         losses = []
         for _ in range(steps):
@@ -114,15 +126,21 @@ def main():
             else:
                 losses.append(torch.stack(train_step(module, opt, data, idx, autocast=not args.fp32_train)))
         losses = torch.stack(losses).cpu().numpy()  # one transfer per iteration, after the last step
+        if graphed is not None:
+            graphed.check()                         # an out-of-range row index in any step of the iteration raises here
         if not np.isfinite(losses).all():
             raise RuntimeError(f"training diverged in iteration {it}: first non-finite loss at step "
                                f"{int(np.argmax(~np.isfinite(losses).all(1)))} of {steps}")
         refresh_device_net(dnet, module)
         t_train = time.time() - t1
+        val_after = validate(dnet, val)    # the refreshed engine net (bf16 MFMA forward) on the same held-out rows
         head, tail = np.mean(losses[: max(1, steps // 10)], axis=0), np.mean(losses[-max(1, steps // 10):], axis=0)
         emit({"what": "iteration", "iter": it, "games": args.games, "plies": plies, "examples": int(len(ex)),
               "augmented_rows": int(len(aug)), "train_rows": int(len(data)), "steps": steps,
               "loss_first_tenth": [round(float(x), 4) for x in head], "loss_last_tenth": [round(float(x), 4) for x in tail],
+              "validation": {"rows": val_after["rows"], "split": args.val_split,
+                             "before": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in val_before.items() if k != "rows"},
+                             "after": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in val_after.items() if k != "rows"}},
               "self_play_x_wins": int((winners > 0).sum()), "self_play_o_wins": int((winners < 0).sum()),
               "self_play_s": round(t_play, 1), "games_per_s": round(args.games / t_play, 1), "train_s": round(t_train, 1),
               "arena": arena("net_bf16", dnet)})

@@ -37,7 +37,8 @@ def run(label, autocast, graph, bench, cl, kernels=False, step_kernels=None, fus
         m = m.to(memory_format=torch.channels_last)
     idx = [torch.randint(0, n, (B,), device="cuda:0") for _ in range(8)]
     if graph:
-        g = GraphedTrainStep(m, lr=1e-3, batch=B, autocast=autocast, tower_kernels=kernels, step_kernels=step_kernels, fused_adam=fused_adam)
+        g = GraphedTrainStep(m, lr=1e-3, batch=B, autocast=autocast, tower_kernels=kernels, step_kernels=step_kernels, fused_adam=fused_adam,
+                             capture_autograd=True)   # ("graph" rows of this table time the CAPTURED forms, autograd ones included)
         step = lambda i: g(ex, idx[i % 8])  # noqa: E731
     else:
         opt = make_optimizer(m, lr=1e-3)

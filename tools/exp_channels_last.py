@@ -151,7 +151,10 @@ def closed_loop(iters=1, seed=0, layout="channels_last", warmup=0, kernels=False
     torch.manual_seed(seed)
     gen = torch.Generator(device="cuda:0").manual_seed(seed)
     module = PolicyValueNet(64, 4, 64, fused_tower=kernels)
-    step = (GraphedTrainStep if kernels else ChannelsLastStep)(module, lr=2e-3, batch=1024, lr_warmup_steps=warmup)
+    # the autograd forms of the step, CAPTURED (the subject of this experiment; GraphedTrainStep's defaults are now the
+    # all-kernel step with the Adam kernel, and autograd steps run eagerly unless capture_autograd=True)
+    step = (GraphedTrainStep if kernels else ChannelsLastStep)(module, lr=2e-3, batch=1024, lr_warmup_steps=warmup,
+                                                              step_kernels=False, fused_adam=False, capture_autograd=True)
     if kernels:  # the product step has no gradient-maximum tail: wrap it
         inner = step._step
 
