@@ -199,6 +199,21 @@ def mcts_search(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None, 
     return N, W, P, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
 
 
+def mcts_search_nodes(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None):
+    """diagnostic: (own[n], opp[n], terminal[n]) of every node one search created, in creation order (node 0 = root)"""
+    cap = sims + 2
+    o, p, t = np.zeros(cap, np.uint64), np.zeros(cap, np.uint64), np.zeros(cap, np.uint8)
+    L = lib()
+    L.orc_mcts_search_nodes.restype = C.c_int
+    L.orc_mcts_search_nodes.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.orc_mcts_search_nodes(game, int(own), int(opp), to_move, sims, eval_kind, c_puct, net.h if net else None, cap,
+                                o.ctypes.data, p.ctypes.data, t.ctypes.data)
+    if n < 0:
+        raise ValueError("terminal root")
+    return o[:n], p[:n], t[:n]
+
+
 def selfplay_game(game, gid, sims, eval_kind, temp_moves=0, openings=0, seed=0, c_puct=1.5, net=None,
                   max_moves=0, dir_alpha=0.0, dir_eps=0.0, reuse=False):
     na = 9 if game == GAME_TTT else 65
