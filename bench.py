@@ -16,7 +16,14 @@ pool runs in steady state: slot g starts pre-advanced by (g % 58) pseudo-random
 plies (untimed setup) and a finished slot immediately starts its next game, so
 every step completes ~B/58 games and value = games completed in the timed
 region / time.  No work is skipped: every move of every game does all 800
-simulations and every non-terminal leaf goes through the full net.
+simulations and every distinct non-terminal position of a search goes through the
+full net.  (A position that a search reaches a second time by another move order --
+6-12 % of a search's leaves -- shares the evaluation of its first occurrence: the
+engine's evaluation cache, BZ_ENGINE_EVAL_CACHE.  Results are bit for bit those
+without it, the tree is the same tree; `roofline` counts only the rows the net
+really computed, the line says how many evaluations were shared, and
+`secondary.cfg3_no_eval_cache` / `--no-eval-cache` run the same workload with every
+leaf through the net.)
 A "step" (ttt) = one complete iteration: all 65,536 games played to the end.
 
 N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL), games sharded
@@ -619,6 +626,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     sp = PipelinedSelfPlay("reversi", B, sims, "net_" + prec, net, pipelines=NS, game_id_base=ctx.rank * B,
                            game_id_stride=ctx.world * B, device=ctx.dev, temp_moves=8, openings=1, seed=0, rounds=rounds,
                            stagger=PLIES_PER_GAME if steady else 0, reuse_subtree=args.reuse_subtree, run_ahead=args.run_ahead,
+                           eval_cache=not args.no_eval_cache,
                            dirichlet_alpha=0.5 if args.dirichlet_eps > 0 else 0.0, dirichlet_eps=args.dirichlet_eps)
     engs, Bs = sp.engines, sp.sizes[0]
     sp.reset_games()
@@ -721,6 +729,11 @@ def run_reversi(ctx, args, B, sims, K, W):
            "config": {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{prec}",
                       "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8, "openings": 12,
                       "evaluator": "policy/value conv tower 6x128 (226.86 MFLOP per leaf), random init seed 0",
+                      "evaluation_cache": ({"on": True, "evaluations_shared": cnt["n_cache_hits"], "evaluations_computed": cnt["n_net_leaves"],
+                                            "shared_fraction": cnt["n_cache_hits"] / max(1, cnt["n_cache_hits"] + cnt["n_net_leaves"]),
+                                            "note": "a position met again inside ONE search takes its first evaluation (bit-identical "
+                                                    "results, tests/test_gpu_parity.py); roofline / net_evals_per_s count computed rows only"}
+                                           if not args.no_eval_cache else {"on": False}),
                       "step": "one move for all concurrent games (steady-state pool, staggered starts)"
                       if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",
                       "pipelines": f"{NS} x {Bs} games on separate HIP streams",
@@ -831,6 +844,9 @@ def main():
                          "the thread then spins on the runtime's full queue, a whole core per rank)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --games per GPU (default, the headline); strong = --games in total, split over the ranks")
+    ap.add_argument("--no-eval-cache", action="store_true",
+                    help="every non-terminal leaf through the net, repeats of a position inside one search included (the engine's "
+                         "evaluation cache off; results are identical either way)")
     ap.add_argument("--reuse-subtree", action="store_true", help="supplementary: keep the chosen child's subtree (DESIGN 3.10)")
     ap.add_argument("--dirichlet-eps", type=float, default=0.0, help="supplementary: root noise weight (alpha 0.5; DESIGN 3.9)")
     ap.add_argument("--force-collective", action="store_true", default=os.environ.get("BZ_BENCH_FORCE_DIST") == "1",
@@ -928,12 +944,15 @@ def main():
                 sec = {}
                 a_fp8 = argparse.Namespace(**{**vars(args), "precision": "fp8", "mode": "steady"})
                 a_iter = argparse.Namespace(**{**vars(args), "mode": "iteration"})
+                a_nocache = argparse.Namespace(**{**vars(args), "no_eval_cache": True, "mode": "steady"})
                 for name, fn in (
                         # cfg 5 as SURVEY 7 reads it: the fp8 net as the in-loop evaluator of 8192 concurrent games
                         ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 6, 2)),
                         # the steady-state figure's cross-check: ONE complete iteration, every game from its
                         # opening to the last finished game, under the same clock
                         ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0)),
+                        # the headline workload with every leaf through the net (evaluation cache off): same results, more rows
+                        ("cfg3_no_eval_cache", lambda: run_reversi(ctx, a_nocache, games, sims, 4, 1)),
                         ("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
                         ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
                         ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3)),

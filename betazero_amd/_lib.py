@@ -15,9 +15,10 @@ EVAL_UNIFORM, EVAL_HASH, EVAL_NET_F32, EVAL_NET_BF16, EVAL_EXTERNAL, EVAL_NET_FP
 ST_RUNNING, ST_TERMINAL, ST_ILLEGAL, ST_MUST_PASS = range(4)
 PASS_ACTION = 64
 ENGINE_REUSE_SUBTREE = 1
+ENGINE_EVAL_CACHE = 2   # BZ_ENGINE_EVAL_CACHE: a position met again inside one search shares its first evaluation
 PROF_SLOTS = ("tower", "stem", "heads", "select", "expand_backup", "search_fused", "play", "env_step")
 COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",
-                 "n_child_written", "n_env_steps", "n_net_leaves")
+                 "n_child_written", "n_env_steps", "n_net_leaves", "n_cache_hits")
 
 u64, u32, i32, i64, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p
 

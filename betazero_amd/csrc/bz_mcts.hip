@@ -57,10 +57,13 @@ __host__ __device__ __forceinline__ u32 e_edge0(u32 w3) { return w3 >> kChildBit
 
 constexpr u32 kTerm = 1u << 8;
 // leaf_kind: NONE = slot idle; EVAL = the leaf awaits (logits, value); TERMINAL = backup of a terminal value;
-// READY = nothing to expand or back up, select at once (a root whose subtree was kept from the previous move)
-enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2, LEAF_READY = 3 };
+// READY = nothing to expand or back up, select at once (a root whose subtree was kept from the previous move);
+// COPY = the leaf's position was evaluated earlier in this search (evaluation cache): its priors and value are copied
+// from that node instead of going through the evaluator again
+enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2, LEAF_READY = 3, LEAF_COPY = 4 };
 enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDED, CNT_CHILD_WRITTEN,
-       CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_N };
+       CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_CACHE_HITS, CNT_N };
+constexpr int kCntWords = 24;  // u64 words of the counters block: CNT_N work counters, then (diagnostic builds) stamps at 16..23
 // NEVAL[2]: packed-leaf counters, double-buffered by simulation parity (the tree step that
 // packs into one buffer zeroes the other, so no extra reset launch is needed)
 enum { FLAG_ERR = 0, FLAG_FINISHED = 1, FLAG_ACTIVE = 2, FLAG_NEVAL = 4, FLAG_N = 8 };
@@ -75,7 +78,8 @@ struct __attribute__((aligned(16))) PathEnt { u32 eidx; u32 w0; float W; u32 pad
 struct __attribute__((aligned(64))) GameHot {
     u64 leaf_legal; u32 leaf_node, leaf_info;   // the leaf awaiting expansion / backup: its legal mask, node id, header
     u32 depth, n_nodes, n_edges, leaf_slot;     // its depth; the tree's fill; the evaluator row of the leaf
-    u32 root_n, root_base, pad[6];              // the root's child count; visits a kept subtree came with (subtree reuse)
+    u32 root_n, root_base;                      // the root's child count; visits a kept subtree came with (subtree reuse)
+    u32 tt_gen, copy_src, copy_e0, pad[3];      // evaluation cache: this search's generation; a COPY leaf's source node, its first edge
 };
 static_assert(sizeof(GameHot) == 64, "layout");
 
@@ -96,12 +100,15 @@ struct EngineDev {
     u32* root_N; float *root_W, *root_P;
     u64* counters; u64* cnt_slots; int n_cnt_slots; u32* flags;
     int32_t* pack_off;  // [rounds][B]: first row of a finished game in the packed example block (k_pack_scan)
+    // evaluation cache (BZ_ENGINE_EVAL_CACHE, net evaluators): per game a hash table position -> node of its first
+    // evaluation in the current search (tt_buckets buckets of 16 eight-byte entries) and every node's value
+    int ecache, tt_buckets; u64* tt; float* node_v;
 };
 
 struct Cnt { u32 v[CNT_N]; };
 
 // Diagnostic build only (betazero_amd.build.build_variant("treestamps", ["-DBZ_EXP_TREE_STAMPS"]), tools/exp_tree_stamps.py):
-// shader-clock stamps between the phases of k_tree_step, summed over all waves into counters[8..15].  The product build
+// shader-clock stamps between the phases of k_tree_step, summed over all waves into counters[16..23].  The product build
 // compiles the empty struct away.
 #if defined(BZ_EXP_TREE_STAMPS) || defined(BZ_EXP_NO_COOP_ENV)
 #ifndef BZ_EXPERIMENT
@@ -115,8 +122,8 @@ struct Stamps {
     __device__ __forceinline__ void mark(int k) { const u64 now = __builtin_readcyclecounter(); acc[k] += (u32)(now - last); last = now; }
     __device__ __forceinline__ void flush(u64* counters) {
         if ((threadIdx.x & 63) == 0) {
-            for (int k = 0; k < 7; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(counters) + 8 + k, (unsigned long long)acc[k]);
-            atomicAdd(reinterpret_cast<unsigned long long*>(counters) + 15, 1ULL);  // waves
+            for (int k = 0; k < 7; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(counters) + 16 + k, (unsigned long long)acc[k]);
+            atomicAdd(reinterpret_cast<unsigned long long*>(counters) + 23, 1ULL);  // waves
         }
     }
 };
@@ -317,9 +324,62 @@ struct CoopChild<G, true> {
 
 // what the walk starts from: the root's position, mover colour and child count (its edges start at index 0)
 // `pre`: this lane's root edge (index sub) when the caller fetched the first kGW root edges ahead of the walk
-struct RootRef { u64 own, opp; int tm; int n; u32 sumN; bool has_pre; Edge pre; };
-// the node select created (valid when a child was created)
-struct LeafPos { u64 own, opp, legal; u32 info; };
+struct RootRef { u64 own, opp; int tm; int n; u32 sumN; bool has_pre; Edge pre; u32 tt_gen; };
+// the node select created (valid when a child was created); src / src_e0: the node whose evaluation a COPY leaf shares
+struct LeafPos { u64 own, opp, legal; u32 info, src, src_e0; };
+
+// ---- evaluation cache.  A search reaches some positions by more than one move order (measured on the CPU oracle: 6 - 12 %
+// of the 800 evaluations of a cfg-3 search, profiles/r05_leaf_duplication.json); the net is a function of the position
+// alone, so the second node takes the first one's priors and value -- bit for bit what the evaluator would have returned
+// -- and no evaluator row.  The TREE is unchanged: the repeat is a node of its own with its own statistics (exact
+// sequential MCTS, the oracle's tree), only the evaluation is shared.  Per game a table of tt_buckets x 16 entries
+// {tag 32 | generation 19 | node 13}; the bucket is one coalesced 128-byte load by the game's lanes; a tag match is
+// CONFIRMED against the stored node's position (a false positive is impossible, whatever the hash does); entries of
+// earlier searches (other generation) are free slots; a full bucket just means no insertion.
+constexpr u32 kTtGenMax = (1u << 19) - 1u;
+template <int kGW>
+__device__ __forceinline__ u32 group_min_u32(u32 x) {
+    if (kGW > 1) { const u32 y = xchg<1>(x); x = y < x ? y : x; }
+    if (kGW > 2) { const u32 y = xchg<2>(x); x = y < x ? y : x; }
+    if (kGW > 4) { const u32 y = xchg<4>(x); x = y < x ? y : x; }
+    if (kGW > 8) { const u32 y = xchg<8>(x); x = y < x ? y : x; }
+    return x;
+}
+// looks (own, opp) up; a confirmed hit returns true with the source node and its first edge; a miss inserts `new_id`
+// (nodes 0 .. n_before - 1 exist and are expanded).  All lanes of the group return the same values.
+template <int kGW>
+__device__ __forceinline__ bool tt_lookup_insert(const EngineDev& E, int g, int sub, const Node* nodes, u64 own, u64 opp, u32 gen,
+                                                 u32 n_before, u32 new_id, u32& src, u32& src_e0) {
+    const u64 h = hash_pos(own, opp);
+    const u32 tag = (u32)(h >> 32);
+    u64* bucket = E.tt + ((size_t)g * (size_t)E.tt_buckets + (size_t)(h & (u64)(E.tt_buckets - 1))) * 16;
+    u32 hit = ~0u, fre = ~0u;  // (slot << 16 | node) of the first matching / first free slot this lane saw
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0 += kGW) {
+        const int s = s0 + sub;
+        const u64 e = bucket[s];
+        const u32 meta = (u32)(e >> 32);
+        const bool cur = (meta >> kChildBits) == gen;
+        if (cur && (u32)e == tag && hit == ~0u) hit = ((u32)s << 16) | (meta & kChildMask);
+        if (!cur && fre == ~0u) fre = (u32)s << 16;
+    }
+    hit = group_min_u32<kGW>(hit);
+    fre = group_min_u32<kGW>(fre);
+    bool found = false;
+    if (hit != ~0u) {
+        const u32 x = hit & kChildMask;
+        if (x != 0u && x < n_before) {
+            const Node xn = nodes[x];  // (one address for the whole group)
+            found = xn.own == own && xn.opp == opp && !(xn.info & kTerm) && (xn.info & 0xFFu) != 0u;
+            src = x; src_e0 = xn.edge0;
+        }
+    }
+    if (!found && fre != ~0u) {
+        const int s = (int)(fre >> 16);
+        if (sub == s % kGW) bucket[s] = (u64)tag | ((u64)((gen << kChildBits) | new_id) << 32);
+    }
+    return found;
+}
 
 // M2: PUCT walk from the root; creates the child node behind the chosen unexpanded edge (env step:
 // apply + legal + terminal).  All lanes of the group return the same values.
@@ -398,6 +458,10 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, c
         else if (lead) atomicOr(&E.flags[FLAG_ERR], ERR_DEPTH);
         depth++;
         leaf = id; kind = term ? LEAF_TERMINAL : LEAF_EVAL; tval = (float)tv;
+        if (E.ecache && !term) {  // evaluated before in this search? (wave-uniform branch: a kernel argument)
+            u32 src = 0, src_e0 = 0;
+            if (tt_lookup_insert<kGW>(E, g, sub, nodes, cown, copp, root.tt_gen, id, id, src, src_e0)) { kind = LEAF_COPY; lp.src = src; lp.src_e0 = src_e0; }
+        }
         st.mark(4);
         break;
     }
@@ -499,6 +563,35 @@ __device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u3
         if (kHeader) *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);  // edge0, info: one 8-byte store
         c.v[CNT_EXPANDED]++;
         c.v[CNT_CHILD_WRITTEN] += (u32)n;
+    }
+    n_edges_g = e0 + (u32)n;
+    return n;
+}
+
+// M3 for a leaf whose position was evaluated earlier in this search (evaluation cache): the same edges -- actions in
+// ascending order, the priors the masked softmax gave the first time, bit for bit -- copied from that node's block;
+// N = 0, W = 0, no child.  legal / info as for dev_expand.  Returns the number of edges written.
+template <class G, int kGW = G::GW>
+__device__ __forceinline__ int dev_expand_copy(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info, u32 src_e0,
+                                               u32& n_edges_g, Cnt& c) {
+    constexpr int kCH = (G::MAXCH + kGW - 1) / kGW;
+    Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
+    const u32 e0 = n_edges_g;
+    Edge* ed = E.edges + (size_t)g * E.ecap + e0;
+    const Edge* from = E.edges + (size_t)g * E.ecap + src_e0;
+    const int room = E.ecap - (int)e0;
+    int n = legal == 0 ? 1 : popc64(legal);
+    if (n > room) { if (sub == 0) atomicOr(&E.flags[FLAG_ERR], ERR_EDGE_OVERFLOW); n = room; }
+    Edge got[kCH];
+#pragma unroll
+    for (int k = 0; k < kCH; ++k) if (sub + kGW * k < n) got[k] = from[sub + kGW * k];
+#pragma unroll
+    for (int k = 0; k < kCH; ++k) if (sub + kGW * k < n) ed[sub + kGW * k] = EdgeFmtPacked::make(got[k].P, e_action(got[k].w0));
+    if (sub == 0) {
+        *reinterpret_cast<uint2*>(&nd->edge0) = make_uint2(e0, (info & ~0xFFu) | (u32)n);
+        c.v[CNT_EXPANDED]++;
+        c.v[CNT_CHILD_WRITTEN] += (u32)n;
+        c.v[CNT_CACHE_HITS]++;
     }
     n_edges_g = e0 + (u32)n;
     return n;
@@ -655,10 +748,11 @@ __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_ro
 }
 
 template <class G>
-__global__ void __launch_bounds__(256) k_root_begin(EngineDev E) {
+__global__ void __launch_bounds__(256) k_root_begin(EngineDev E, u32 tt_gen) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     uint8_t kind = LEAF_NONE;
+    E.hot[g].tt_gen = tt_gen;  // entries of earlier searches in the evaluation cache are free slots from now on
     const u32 keep = (E.reuse && E.g_state[g] == 0) ? E.g_reuse[g] : 0u;
     if (keep) {
         dev_reroot<G>(E, g, keep);
@@ -755,7 +849,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
         pin(nlegal); pin(rown); pin(ropp); pin(root_base); pin(pe0.eidx); pin(pe0.w0); pin(pe0.W);
         const bool active = state == 0 && kind != LEAF_NONE;
         st.mark(0);
-        if (do_expand && (kind == LEAF_EVAL || kind == LEAF_TERMINAL)) {
+        if (do_expand && (kind == LEAF_EVAL || kind == LEAF_TERMINAL || kind == LEAF_COPY)) {
             float v;
             u32 e0 = ne; int n = 0;
             if (kind == LEAF_EVAL) {  // ---- round trip 2: the evaluator's row
@@ -763,8 +857,15 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 v = E.value[row];
                 if (sub == 0 && !(v >= -3.0e38f && v <= 3.0e38f)) atomicOr(&E.flags[FLAG_ERR], ERR_EVAL_NONFINITE);
                 n = dev_expand<G>(E, g, sub, leaf, nlegal, ninfo, ls, ne, c, st);
-                if (sub == 0) { E.hot[g].n_edges = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.hot[g].root_n = (u32)n; }
+                if (sub == 0) {
+                    E.hot[g].n_edges = ne; c.v[CNT_NET_LEAVES]++; if (leaf == 0) E.hot[g].root_n = (u32)n;
+                    if (E.ecache) E.node_v[(size_t)g * E.ncap + leaf] = v;  // what a later repeat of this position copies
+                }
                 if (leaf == 0) { root_n = n; pre_ok = false; }  // the root's edges did not exist when re0 was fetched
+            } else if (kind == LEAF_COPY) {  // ---- round trip 2: the first evaluation's edges and value (evaluation cache)
+                v = E.node_v[(size_t)g * E.ncap + hot.copy_src];
+                n = dev_expand_copy<G>(E, g, sub, leaf, nlegal, ninfo, hot.copy_e0, ne, c);
+                if (sub == 0) { E.hot[g].n_edges = ne; E.node_v[(size_t)g * E.ncap + leaf] = v; }
             } else {
                 v = (float)((int)((ninfo >> 9) & 3u) - 1);
             }
@@ -790,9 +891,9 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
             if (active) {
                 group_fence();  // edges written above are read below
                 u32 leaf2; int k2, depth; float tv;
-                LeafPos lpos; lpos.own = 0; lpos.opp = 0; lpos.legal = 0; lpos.info = 0;
+                LeafPos lpos; lpos.own = 0; lpos.opp = 0; lpos.legal = 0; lpos.info = 0; lpos.src = 0; lpos.src_e0 = 0;
                 RootRef root; root.own = rown; root.opp = ropp; root.tm = rtm; root.n = root_n;
-                root.sumN = sim_idx + root_base; root.has_pre = pre_ok; root.pre = re0;
+                root.sumN = sim_idx + root_base; root.has_pre = pre_ok; root.pre = re0; root.tt_gen = hot.tt_gen;
                 PathHbm<kGW> sink; sink.p = path; sink.mine.eidx = 0; sink.mine.w0 = 0; sink.mine.W = 0.0f; sink.mine.pad = 0;
                 dev_select<G>(E, g, sub, root, nn, leaf2, k2, depth, tv, c, sink, lpos, st);  // ---- one round trip per level
                 sink.flush(sub, depth);
@@ -801,6 +902,9 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                     if (k2 == LEAF_EVAL) {  // only an evaluated leaf's position is consumed (evaluator input)
                         E.leaf_own[g] = lpos.own; E.leaf_opp[g] = lpos.opp; E.hot[g].leaf_legal = lpos.legal; E.hot[g].leaf_info = lpos.info;
                         if (E.compact) { want_slot = true; my_rank = atomicAdd(&s_need, 1u); slot_own = lpos.own; slot_opp = lpos.opp; }
+                    } else if (k2 == LEAF_COPY) {  // its evaluation exists already: no evaluator row, the next step copies it
+                        E.hot[g].leaf_legal = lpos.legal; E.hot[g].leaf_info = lpos.info;
+                        E.hot[g].copy_src = lpos.src; E.hot[g].copy_e0 = lpos.src_e0;
                     } else {  // terminal leaf (new or revisited): the backup needs its value only
                         E.hot[g].leaf_info = (u32)((int)tv + 1) << 9;
                     }
@@ -1253,6 +1357,7 @@ struct bz_engine {
     int64_t bytes;
     int pack_parity;  // which NEVAL buffer the last root_begin / select packed into
     int ttt_gw;       // lanes per game of the TTT-specialised fused search (cfg.ttt_lanes; 0 = the generic any-game kernel)
+    uint32_t search_seq;  // searches begun so far: the evaluation cache's generation (entries of earlier searches are dead)
     // bz_engines_step: ring of blocking-sync events that bounds how far the host thread runs ahead of this engine's
     // stream (created on first use)
     hipEvent_t ahead[4];
@@ -1268,10 +1373,12 @@ struct Carver {
 struct Offsets {
     int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, hot,
         path, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
-        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, pack_off, total;
+        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, pack_off, tt, node_v, total;
     int n_cnt_slots;
     int ncap, ecap, na, maxd;
+    int ecache, tt_buckets;
 };
+inline bool net_eval(int ek) { return ek == BZ_EVAL_NET_F32 || ek == BZ_EVAL_NET_BF16 || ek == BZ_EVAL_NET_FP8; }
 
 // nodes a game's arena holds: a fresh tree grows by one node per simulation; with subtree reuse a kept
 // subtree + sims new nodes must fit
@@ -1317,11 +1424,18 @@ Offsets carve(const bz_engine_cfg& c) {
     // ex_own .. ex_meta are consecutive: ONE byte range [ex_own, ex_meta + 256) is what the all-gather ships
     o.ex_meta = k.take(256);
     o.root_N = k.take(B * o.na * 4); o.root_W = k.take(B * o.na * 4); o.root_P = k.take(B * o.na * 4);
-    o.counters = k.take(16 * 8);
+    o.counters = k.take(kCntWords * 8);
     o.n_cnt_slots = (int)((B * 16 + 63) / 64) + 4;  // one slot per wave of the widest (group) launch (<= 16 lanes per game)
     o.cnt_slots = k.take((int64_t)o.n_cnt_slots * CNT_N * 8);
     o.flags = k.take(FLAG_N * 4);
     o.pack_off = k.take(R * B * 4);
+    // evaluation cache: net evaluators only (a synthetic evaluation costs less than the lookup), not with subtree reuse
+    // (a kept subtree's nodes are not in the new search's table).  Buckets: a power of two, >= 2 slots per node
+    o.ecache = ((c.flags & BZ_ENGINE_EVAL_CACHE) && net_eval(c.eval_kind) && !reuse) ? 1 : 0;
+    o.tt_buckets = 16;
+    while ((int64_t)o.tt_buckets * 16 < 2 * (int64_t)o.ncap) o.tt_buckets *= 2;
+    o.tt = k.take(o.ecache ? B * o.tt_buckets * 16 * 8 : 0);
+    o.node_v = k.take(o.ecache ? B * o.ncap * 4 : 0);
     o.total = k.off;
     return o;
 }
@@ -1364,7 +1478,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_engine_create: workspace must be 256-byte aligned");
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
-    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1; e->n_ahead = 0;
+    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1; e->n_ahead = 0; e->search_seq = 0;
     // measured on MI355X at 65,536 games x 50 sims: round 2 (profiles/r02_bench_ttt_gw*) 2 lanes 0.185 ms, 4 lanes 0.190 ms,
     // 8 lanes 0.294 ms per launch; round 3, after the kernel became issue-bound and lost a third of its instructions
     // (profiles/r03_bench_ttt_lanes.txt): 1 lane 0.162, 2 lanes 0.137, 4 lanes 0.134, 8 lanes 0.181 ms -> 4 lanes
@@ -1385,8 +1499,12 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.leaf_kind = at<uint8_t>(ws, o.leaf_kind);
     d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
     d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp);
-    d.compact = (cfg->eval_kind == BZ_EVAL_NET_F32 || cfg->eval_kind == BZ_EVAL_NET_BF16 ||
-                 cfg->eval_kind == BZ_EVAL_NET_FP8) ? 1 : 0;
+    d.compact = net_eval(cfg->eval_kind) ? 1 : 0;
+    d.ecache = o.ecache; d.tt_buckets = o.tt_buckets; d.tt = at<u64>(ws, o.tt); d.node_v = at<float>(ws, o.node_v);
+    if (o.ecache) {  // generation 0 = never written
+        hipError_t ce = hipMemset(d.tt, 0, (size_t)cfg->n_games * o.tt_buckets * 16 * 8);
+        if (ce != hipSuccess) { delete e; return hip_fail(ce, "bz_engine_create: evaluation-cache clear"); }
+    }
     d.logits = at<float>(ws, o.logits); d.value = at<float>(ws, o.value);
     d.ex_own = at<u64>(ws, o.ex_own); d.ex_opp = at<u64>(ws, o.ex_opp); d.ex_pi = at<float>(ws, o.ex_pi);
     d.ex_z = at<int8_t>(ws, o.ex_z); d.ex_mover = at<int8_t>(ws, o.ex_mover); d.ex_act = at<uint8_t>(ws, o.ex_act);
@@ -1436,7 +1554,7 @@ BZ_EXPORT int32_t bz_engine_set_net(bz_engine* e, bz_net* net) {
 
 BZ_EXPORT int32_t bz_engine_reset_counters(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
-    BZ_HIP(hipMemsetAsync(e->dev.counters, 0, 16 * 8, (hipStream_t)stream));
+    BZ_HIP(hipMemsetAsync(e->dev.counters, 0, kCntWords * 8, (hipStream_t)stream));
     BZ_HIP(hipMemsetAsync(e->dev.cnt_slots, 0, (size_t)e->dev.n_cnt_slots * CNT_N * 8, (hipStream_t)stream));
     return BZ_OK;
 }
@@ -1465,7 +1583,8 @@ BZ_EXPORT int32_t bz_engine_set_roots(bz_engine* e, const uint64_t* own, const u
 
 BZ_EXPORT int32_t bz_engine_root_begin(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
-    BZ_DISPATCH(e, k_root_begin, stream, e->dev);
+    e->search_seq = e->search_seq % (kTtGenMax - 1u) + 1u;  // 1 .. 2^19 - 2 (0 = never written)
+    BZ_DISPATCH(e, k_root_begin, stream, e->dev, e->search_seq);
     e->pack_parity = 1;
     return BZ_OK;
 }

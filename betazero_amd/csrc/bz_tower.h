@@ -130,7 +130,7 @@ template <int C_, int P_ = 512 / C_, bool M16_ = false> struct Tw {
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
-#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER) || defined(BZ_EXP_MFMA16)) && !defined(BZ_EXPERIMENT)
+#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER) || defined(BZ_EXP_MFMA16) || defined(BZ_EXP_MFMA_AMAJOR)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
 // weight-fragment loads of the bf16 tower.  Diagnostic option BZ_EXP_WEIGHTS_NT: non-temporal loads, to see whether the
@@ -445,11 +445,23 @@ __device__ __forceinline__ void mfma16_quarter(f32x16& c, const bf16x8& a, const
 template <class G, int TAP, int HALF>
 __device__ __forceinline__ void mfma_units16(f32x16 (&acc)[G::MW][G::NU], const bf16x8 (&a)[2], const bf16x8 (&b)[G::NU]) {
     constexpr int dy = TAP / 3 - 1;
+#ifdef BZ_EXP_MFMA_AMAJOR
+    // diagnostic A/B (tools/exp_ab_mfma_order.sh): the same MFMAs, channel-half-major -- consecutive MFMAs then share the
+    // WEIGHT operand and change the activation operand, instead of sharing the activations and alternating the weights.
+    // Every accumulator quarter sees the same sequence of products: outputs are bit-identical.  The kernel is power-bound
+    // (1320 W at 2.0 GHz on random data against 985 W at 2.4 GHz on zero weights, profiles/r01_power_clock_rocm_smi.txt), so
+    // the question is whether one issue order costs less energy per MFMA than the other.
+#pragma unroll
+    for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u) mfma16_quarter<HALF>(acc[0][u], a[0], b[u]);
+#pragma unroll
+    for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u) mfma16_quarter<2 + HALF>(acc[0][u], a[1], b[u]);
+#else
 #pragma unroll
     for (int u = G::unit_lo(dy); u < G::unit_hi(dy); ++u) {
         mfma16_quarter<HALF>(acc[0][u], a[0], b[u]);      // a = 0: quarter b
         mfma16_quarter<2 + HALF>(acc[0][u], a[1], b[u]);  // a = 1: quarter 2 + b
     }
+#endif
 }
 // one conv tap: 2 KQ sub-steps; the register set freed by the previous tap is filled for the next one
 template <int S, int TAP, class G>

@@ -228,6 +228,14 @@ typedef struct bz_engine_cfg {
 /* keep the chosen child's subtree as the next search's tree; searches then go through the
  * step kernels for every evaluator */
 #define BZ_ENGINE_REUSE_SUBTREE 1u
+/* Evaluation cache (net evaluators; ignored with the synthetic / external evaluators and with BZ_ENGINE_REUSE_SUBTREE):
+ * a leaf whose position was already evaluated earlier in the SAME search -- reached by another move order -- takes that
+ * node's priors and value instead of an evaluator row.  The evaluator is a function of the position alone
+ * (players.py:84-98: canonical planes in, logits out), so every result (visit counts, W, P, pi, moves) is bit for
+ * bit what it is without the cache -- the tree is the same tree, only the repeated forward is not run.  The work counters
+ * say how often: counters[8] = repeats served from the cache, counters[7] = rows the evaluator computed; their sum is
+ * what counters[7] reads without the cache.  A table hit is confirmed against the stored node's position before use. */
+#define BZ_ENGINE_EVAL_CACHE 2u
 
 /* offsets (bytes, from the workspace base) of the caller-visible arrays */
 typedef struct bz_engine_layout {
@@ -243,7 +251,7 @@ typedef struct bz_engine_layout {
     int64_t logits, value;          /* f32 [B][NA], f32 [B]  evaluator outputs        */
     int64_t g_own, g_opp;           /* u64 [B] current positions                      */
     int64_t g_to_move, g_state;     /* i8 / u8 [B]  (state: 0 active, 1 finished)     */
-    int64_t counters;               /* u64 [16] work counters           */
+    int64_t counters;               /* u64 [24] work counters: 0..8 used */
     int32_t na, t_max;
     /* The example arrays ex_own .. ex_winner are consecutive in the workspace and are followed by
      * a 256-byte header (ex_meta: u64 magic, game_id_base, game_id_stride, B, rounds, t_max, NA,

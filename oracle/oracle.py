@@ -184,6 +184,14 @@ def gamma(alpha, seed, gid, ply, edge):
     return np.float32(lib().orc_gamma(float(np.float32(alpha)), seed, gid, ply, edge))
 
 
+def _counters(cnt):
+    """the oracle's 8 work counters under the engine's names; the oracle has no evaluation cache (every leaf is evaluated),
+    so the engine's ninth counter reads 0 here"""
+    d = dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
+    d["n_cache_hits"] = 0
+    return d
+
+
 def mcts_search(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None, dir_alpha=0.0, dir_eps=0.0, seed=0,
                 gid=0, ply=0):
     na = 9 if game == GAME_TTT else 65
@@ -196,7 +204,7 @@ def mcts_search(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None, 
                                      N.ctypes.data, W.ctypes.data, P.ctypes.data, cnt.ctypes.data)
     if rc:
         raise ValueError("terminal root")
-    return N, W, P, dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
+    return N, W, P, _counters(cnt)
 
 
 def mcts_search_nodes(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None):
@@ -231,4 +239,4 @@ def selfplay_game(game, gid, sims, eval_kind, temp_moves=0, openings=0, seed=0, 
                                 cnt.ctypes.data)
     z = (w.value * mover[:n]).astype(np.int8) if w.value in (-1, 0, 1) else np.zeros(n, np.int8)
     return {"own": own[:n], "opp": opp[:n], "pi": pi[:n], "mover": mover[:n], "act": act[:n], "z": z,
-            "winner": w.value, "passes": p.value, "counters": dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))}
+            "winner": w.value, "passes": p.value, "counters": _counters(cnt)}

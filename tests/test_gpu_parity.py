@@ -1085,13 +1085,57 @@ def test_cfg3_full_size_4096_games_800_sims_bf16_net_invariants(ev, B, stagger):
         del nex_before
     cnt = eng.counters()
     assert cnt["n_sims"] == roots * sims
-    assert cnt["n_net_leaves"] == cnt["n_expanded"]              # every expansion consumed one net evaluation
-    assert cnt["n_env_steps"] <= cnt["n_sims"] and cnt["n_net_leaves"] - roots <= cnt["n_env_steps"]
+    # every expansion consumed one evaluation: computed by the net, or shared with an earlier node of the same search that
+    # holds the same position (the evaluation cache, on by default with a net evaluator)
+    evals = cnt["n_net_leaves"] + cnt["n_cache_hits"]
+    assert evals == cnt["n_expanded"] and 0 < cnt["n_cache_hits"] < 0.3 * evals
+    assert cnt["n_env_steps"] <= cnt["n_sims"] and evals - roots <= cnt["n_env_steps"]
     assert cnt["n_child_written"] >= cnt["n_expanded"]
-    if stagger == 0:  # no terminal inside an 800-sim tree from the openings: every simulation ends in the net
-        assert cnt["n_net_leaves"] == cnt["n_sims"] + roots and cnt["n_env_steps"] == cnt["n_sims"]
+    if stagger == 0:  # no terminal inside an 800-sim tree from the openings: every simulation ends in an evaluation
+        assert evals == cnt["n_sims"] + roots and cnt["n_env_steps"] == cnt["n_sims"]
     else:             # late-game slots do reach terminals
-        assert cnt["n_net_leaves"] < cnt["n_sims"] + roots
+        assert evals < cnt["n_sims"] + roots
+
+
+@pytest.mark.parametrize("ev,game,B,sims", [("net_bf16", "reversi", 384, 800), ("net_f32", "reversi6", 40, 300), ("net_fp8", "reversi", 300, 200)],
+                         ids=["bf16_800", "f32_6x6_300", "fp8_200"])
+def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, sims):
+    """BZ_ENGINE_EVAL_CACHE: a leaf whose position was evaluated earlier in the same search takes that node's priors and
+    value instead of an evaluator row.  Against the SAME engine without the cache, from all game phases (staggered
+    pool) and over two moves: root N / W / P of every game bit for bit, the played moves and the example rows bit for bit,
+    every work counter equal -- except that the evaluator computed fewer rows: n_net_leaves(on) + n_cache_hits ==
+    n_net_leaves(off), with hits > 3 % (the CPU measurement on the oracle, profiles/r05_leaf_duplication.json: 6 - 12 %).
+    (That the cache-ON engine equals the ORACLE, which has no cache, is what every net-evaluator parity test checks.)"""
+    from betazero_amd.net import DeviceNet
+    mod = _net(128, 6, bf16=True) if ev != "net_f32" else _net(32, 2, seed=3)
+    if ev == "net_fp8":
+        from betazero_amd.quant import fake_quantize_fp8_
+        fake_quantize_fp8_(mod)
+    dn = DeviceNet.from_module(mod, B)
+    kw = dict(net=dn, temp_moves=8, openings=1, seed=2, rounds=2, stagger=58 if game == "reversi" else 20)
+    on, off = _engine(game, B, sims, ev, eval_cache=True, **kw), _engine(game, B, sims, ev, eval_cache=False, **kw)
+    for e in (on, off):
+        e.reset_games(); e.reset_counters()
+    for mv in range(2):
+        for e in (on, off):
+            e.search()
+        (N1, W1, P1), (N0, W0, P0) = on.root_stats(), off.root_stats()
+        assert np.array_equal(N1, N0) and np.array_equal(W1.view(np.uint32), W0.view(np.uint32)) and np.array_equal(P1.view(np.uint32), P0.view(np.uint32)), mv
+        for e in (on, off):
+            e.play(True)
+    assert on.status() == off.status()
+    a, b = on.example_tensors(), off.example_tensors()
+    for f in ("own", "opp", "act", "mover", "len"):
+        assert torch.equal(a[f], b[f]), f
+    assert torch.equal(a["pi"].view(torch.int32), b["pi"].view(torch.int32))
+    c1, c0 = on.counters(), off.counters()
+    for k in c1:
+        if k not in ("n_net_leaves", "n_cache_hits"):
+            assert c1[k] == c0[k], (k, c1[k], c0[k])
+    assert c0["n_cache_hits"] == 0 and c1["n_net_leaves"] + c1["n_cache_hits"] == c0["n_net_leaves"]
+    frac = c1["n_cache_hits"] / c0["n_net_leaves"]
+    print(f"evaluation cache, {ev} {game} {B} games x {sims} sims: {c1['n_cache_hits']} of {c0['n_net_leaves']} evaluations shared = {frac:.3f}")
+    assert frac > (0.03 if sims >= 300 else 0.01)   # (a 200-simulation tree meets fewer transpositions than an 800-simulation one)
 
 
 def test_cfg3_800_sims_bf16_net_search_close_to_oracle_bf16_emulation():
@@ -1801,7 +1845,7 @@ def test_cfg3_full_size_two_pipelines_equal_one_engine_bit_for_bit():
     got = torch.cat([t["pi"][0, :, :2] for t in a]).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), b["pi"][0, :, :2].cpu().numpy().view(np.uint32))
     ca, cb = sp.counters(), one.counters()
-    assert ca == cb and ca["n_sims"] == 2 * B * sims and ca["n_net_leaves"] == ca["n_sims"] + 2 * B, (ca, cb)
+    assert ca == cb and ca["n_sims"] == 2 * B * sims and ca["n_net_leaves"] + ca["n_cache_hits"] == ca["n_sims"] + 2 * B, (ca, cb)
 
 
 def test_bench_two_ranks_end_to_end_on_one_gpu_gloo():

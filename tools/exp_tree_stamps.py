@@ -23,8 +23,8 @@ eng.reset_counters()
 eng.search(); eng.play(True)
 torch.cuda.synchronize()
 eng._call(__import__("betazero_amd._lib", fromlist=["lib"]).lib().bz_engine_sum_counters)
-c = eng._view(eng.lay.counters, torch.int64, (16,)).cpu().numpy()
-waves = max(int(c[15]), 1)
+c = eng._view(eng.lay.counters, torch.int64, (24,)).cpu().numpy()   # work counters 0..8, stamps 16..22, waves 23
+waves = max(int(c[23]), 1)
 launches = sims + 1
 names = ["T0: per-game words + path (1 round trip)", "T1: evaluator row arrives", "expansion (softmax, edge stores) + backup stores",
          "select walk (all levels)", "child creation (apply / legal / terminal)", "tail (leaf words, slot atomic, path flush)",
@@ -32,7 +32,7 @@ names = ["T0: per-game words + path (1 round trip)", "T1: evaluator row arrives"
 tot = 0
 print(f"k_tree_step stamps: {waves} wave-executions over {launches} launches ({waves / launches:.0f} per launch), B = {B}, sims = {sims}")
 for k, nm in enumerate(names):
-    v = c[8 + k] / waves
+    v = c[16 + k] / waves
     tot += v
     print(f"  {nm:60s} {v:9.0f} cycles per wave")
 print(f"  {'sum of stamped phases':60s} {tot:9.0f} cycles per wave")
