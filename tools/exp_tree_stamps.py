@@ -15,7 +15,8 @@ sims = int(sys.argv[1]) if len(sys.argv) > 1 else 800
 B = int(os.environ.get("GAMES", "4096"))
 torch.manual_seed(0)
 net = DeviceNet.from_module(PolicyValueNet(128, 6, 64).round_to_bf16_(), B)
-eng = SelfPlayEngine("reversi", B, sims, "net_bf16", net, temp_moves=8, openings=1, rounds=4, stagger=58)
+CACHE = os.environ.get("EVAL_CACHE", "1") != "0"   # EVAL_CACHE=0: the engine's evaluation cache off (what the lookup costs the tree step)
+eng = SelfPlayEngine("reversi", B, sims, "net_bf16", net, temp_moves=8, openings=1, rounds=4, stagger=58, eval_cache=CACHE)
 eng.reset_games()
 eng.search(); eng.play(True)          # warm-up move
 torch.cuda.synchronize()
@@ -30,6 +31,7 @@ names = ["T0: per-game words + path (1 round trip)", "T1: evaluator row arrives"
          "select walk (all levels)", "child creation (apply / legal / terminal)", "tail (leaf words, slot atomic, path flush)",
          "work-counter flush"]
 tot = 0
+print(f"evaluation cache {'on' if CACHE else 'off'}: {c[8]} of {c[7] + c[8]} evaluations shared")
 print(f"k_tree_step stamps: {waves} wave-executions over {launches} launches ({waves / launches:.0f} per launch), B = {B}, sims = {sims}")
 for k, nm in enumerate(names):
     v = c[16 + k] / waves
