@@ -51,7 +51,7 @@ MFMA_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICRO
 HBM_PEAK_GBS = 8000.0
 PLIES_PER_GAME = 58                                   # searched moves per cfg-3 game (60 - 2 opening plies)
 WHOLE_GAME_SIMS = 32                                  # cpu_baseline.whole_game: complete games on the C port at this many sims/move
-PMC_TRAFFIC = ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
+PMC_TRAFFIC = ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json")
 
 
 def tree_bytes(c):
@@ -778,11 +778,11 @@ def run_reversi(ctx, args, B, sims, K, W):
         ppl = flop_per_launch / NET_FLOP_PER_POS
         for path in PMC_TRAFFIC:
             try:
-                tr = json.load(open(os.path.join(ROOT, path)))["k_tower_bf16"]
+                tr = json.load(open(os.path.join(ROOT, path)))["k_tower_bf16" if prec == "bf16" else "k_tower_fp8@selfplay"]
             except Exception:
                 continue
             tp = float(tr.get("positions_per_launch", 4096))
-            if prec == "bf16" and abs(tp - ppl) <= 0.1 * ppl:
+            if abs(tp - ppl) <= 0.1 * ppl:
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command ({path}: "
                                                      f"{tp:.0f} positions per launch; this run: {ppl:.0f})")

@@ -236,9 +236,9 @@ __device__ __forceinline__ void build_ray_table(RayEnt* tab /* [64][4] */) {
     }
 }
 __device__ __forceinline__ u64 ray_flips_up(u64 P, u64 O, RayEnt e) {
-    const u64 of = ((O | e.nm) + 1ULL) & e.m & P;      // the mover's stone that closes the run, or 0
+    const u64 of = and3((O | e.nm) + 1ULL, e.m, P);    // the mover's stone that closes the run, or 0
     const u64 x = of - 1ULL;                            // of == 0 -> all ones (bit 63 set); else the bits below it
-    return x & e.m & ~(u64)((int64_t)x >> 63);
+    return and_andn(x, e.m, (u64)((int64_t)x >> 63));
 }
 // flips of placing on square a (the cell must be empty); me = mover's stones
 __device__ __forceinline__ u64 rev_flips_carry(u64 me, u64 you, int a, const RayEnt* tab) {
@@ -263,22 +263,25 @@ __device__ __forceinline__ u64 rev_flips_carry(u64 me, u64 you, int a, const Ray
 // With 4 games per lane and 64 lanes, "rare" (a per cent of the games) would otherwise mean "in nearly every wave, for
 // every one of the 4 game slots": ~80 extra instructions per game.
 struct StepOut { u64 cown, copp, nl; uint8_t st; int8_t w; };
+// (round 5) ONE code path for the three kinds of action.  A pass, a placement and an illegal placement all end in
+// "the legal mask of whoever moves in the resulting position", so the position is chosen with selects and rev_legal
+// appears once (it was compiled three times -- pass / nothing flipped / placement -- and a wave in which one lane passes
+// executed two of the copies for that game slot).
 __device__ __forceinline__ bool step_main(u64 me, u64 you, int a, u64 valid, const RayEnt* tab, StepOut& o, u64& jx, u64& jy) {
-    o.cown = me; o.copp = you; o.st = BZ_ST_ILLEGAL; o.w = 0; o.nl = 0;
-    jx = me; jy = you;
-    if (a == kPass) {  // tentatively accepted; step_finish checks that the mover really had no move
-        o.cown = you; o.copp = me;
-        o.nl = rev_legal(o.cown, o.copp, valid);
-        return true;
-    }
-    const u64 m = a < 64 ? (1ULL << a) & valid : 0ULL;
-    const u64 f = (m & ~(me | you)) ? rev_flips_carry(me, you, a, tab) : 0ULL;
-    if (f == 0) { o.nl = rev_legal(me, you, valid); return false; }  // illegal placement: position unchanged
-    o.cown = you & ~f; o.copp = me | m | f;
+    const bool pass = a == kPass;
+    const u64 m = a < 64 ? (1ULL << (a & 63)) & valid : 0ULL;
+    const u64 f = (m & ~(me | you)) ? rev_flips_carry(me, you, a & 63, tab) : 0ULL;   // (skipped by lanes that pass or hit a stone)
+    const bool placed = f != 0;            // a placement is legal iff the cell is empty and it flips something
+    const bool moved = pass || placed;     // the side changes; an illegal placement leaves the position as it was
+    o.cown = moved ? (you & ~f) : me;      // (f = 0 for a pass)
+    o.copp = moved ? (me | (placed ? m : 0ULL) | f) : you;
     o.nl = rev_legal(o.cown, o.copp, valid);
-    o.st = BZ_ST_RUNNING;
-    jx = o.copp; jy = o.cown;
-    return o.nl == 0;
+    o.st = placed ? BZ_ST_RUNNING : BZ_ST_ILLEGAL;   // (a pass is settled by step_finish)
+    o.w = 0;
+    // one more legal mask J finishes the rare cases: the mover's own (a pass is legal only if it is empty), or the mask
+    // of the player who just placed a stone when the next mover has no move (MUST_PASS vs TERMINAL)
+    jx = pass ? me : o.copp; jy = pass ? you : o.cown;
+    return pass || (placed && o.nl == 0);
 }
 __device__ __forceinline__ void step_finish(u64 me, u64 you, int a, u64 J, StepOut& o) {
     if (a == kPass && J != 0) {  // the mover had a move: the pass is illegal, nothing changes

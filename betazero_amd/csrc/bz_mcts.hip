@@ -286,10 +286,10 @@ __device__ __forceinline__ u64 or8(u64 x) {  // OR over the 8 lanes of a half ro
 // stones pre-masked against column wrap; runs of <= 6 stones by parallel prefix (2 + 2 + 2 cells)
 __device__ __forceinline__ u64 ray_fill(u64 seed, u64 o, int s) {
     u64 fl = o & (seed << s);
-    fl |= o & (fl << s);
+    fl = and_or(o, fl << s, fl);
     const u64 pl = o & (o << s);
-    fl |= pl & (fl << (2 * s));
-    fl |= pl & (fl << (2 * s));
+    fl = and_or(pl, fl << (2 * s), fl);
+    fl = and_or(pl, fl << (2 * s), fl);
     return fl;
 }
 template <class G, bool kShare = (G::kGame != 0 && G::GW >= 8)>

@@ -34,6 +34,26 @@ BZ_HD int ctz64(u64 x) {
 #endif
 }
 
+// three-input bit logic on 64-bit boards.  gfx950 has v_bitop3_b32 (any boolean function of three words in one
+// instruction), but the compiler splits 64-bit and / or / andn into halves too late to form it (the env step's ISA showed
+// v_and + v_or pairs throughout), so the device side asks for it per half; the host side is the plain expression.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <unsigned TT> __device__ __forceinline__ u64 bitop3_64(u64 a, u64 b, u64 c) {
+    const u32 lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, TT);
+    const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), TT);
+    return ((u64)hi << 32) | lo;
+}
+BZ_HD u64 and_or(u64 a, u64 b, u64 c) { return bitop3_64<0xEA>(a, b, c); }     // (a & b) | c
+BZ_HD u64 and3(u64 a, u64 b, u64 c) { return bitop3_64<0x80>(a, b, c); }       // a & b & c
+BZ_HD u64 and_andn(u64 a, u64 b, u64 c) { return bitop3_64<0x40>(a, b, c); }   // a & b & ~c
+BZ_HD u64 andn2(u64 a, u64 b, u64 c) { return bitop3_64<0x10>(a, b, c); }      // a & ~b & ~c
+#else
+BZ_HD u64 and_or(u64 a, u64 b, u64 c) { return (a & b) | c; }
+BZ_HD u64 and3(u64 a, u64 b, u64 c) { return a & b & c; }
+BZ_HD u64 and_andn(u64 a, u64 b, u64 c) { return a & b & ~c; }
+BZ_HD u64 andn2(u64 a, u64 b, u64 c) { return a & ~b & ~c; }
+#endif
+
 BZ_HD u64 rev_valid(int size) {
     u64 row = (1ULL << size) - 1ULL;
     u64 m = 0;
@@ -45,10 +65,10 @@ BZ_HD u64 rev_valid(int size) {
 // opponent stones; o is opp pre-masked against wrap for this direction.
 BZ_HD u64 rev_moves_dir(u64 own, u64 o, int s) {
     u64 fl = o & (own << s), fr = o & (own >> s);
-    fl |= o & (fl << s);      fr |= o & (fr >> s);
+    fl = and_or(o, fl << s, fl);         fr = and_or(o, fr >> s, fr);
     u64 pl = o & (o << s),    pr = o & (o >> s);
-    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
-    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    fl = and_or(pl, fl << (2 * s), fl);  fr = and_or(pr, fr >> (2 * s), fr);
+    fl = and_or(pl, fl << (2 * s), fl);  fr = and_or(pr, fr >> (2 * s), fr);
     return (fl << s) | (fr >> s);
 }
 
@@ -78,7 +98,7 @@ BZ_HD u64 rev_legal(u64 own, u64 opp, u64 valid) {
     u64 oh = opp & kInner;
     u64 m = rev_moves_ew(own, oh) | rev_moves_dir(own, opp, 8) | rev_moves_dir(own, oh, 7) |
             rev_moves_dir(own, oh, 9);
-    return m & ~(own | opp) & valid;
+    return andn2(m, own, opp) & valid;
 }
 BZ_HD u64 rev_legal8(u64 own, u64 opp) { return rev_legal(own, opp, ~0ULL); }
 
@@ -87,10 +107,10 @@ BZ_HD u64 rev_legal8(u64 own, u64 opp) { return rev_legal(own, opp, ~0ULL); }
 BZ_HD u64 rev_flips_dir(u64 own, u64 o, u64 m, int s) {
     // runs of <= 6 opponent stones next to m, parallel-prefix (2 + 2 + 2 cells)
     u64 fl = o & (m << s), fr = o & (m >> s);
-    fl |= o & (fl << s);      fr |= o & (fr >> s);
+    fl = and_or(o, fl << s, fl);         fr = and_or(o, fr >> s, fr);
     u64 pl = o & (o << s),    pr = o & (o >> s);
-    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
-    fl |= pl & (fl << (2 * s)); fr |= pr & (fr >> (2 * s));
+    fl = and_or(pl, fl << (2 * s), fl);  fr = and_or(pr, fr >> (2 * s), fr);
+    fl = and_or(pl, fl << (2 * s), fl);  fr = and_or(pr, fr >> (2 * s), fr);
     u64 out = 0;
     if ((fl << s) & own) out |= fl;
     if ((fr >> s) & own) out |= fr;

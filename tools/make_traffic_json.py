@@ -39,6 +39,8 @@ for key, name, kern, shape, cmd in (
         ("k_search_fused_ttt", "pmc_ttt", "k_search_fused_ttt", {"games": 65536, "sims": 50, "ttt_lanes": 4},
          "python3 bench.py --workload ttt --ttt-lanes 4 --steps 2 --warmup 1 --no-cpu-baseline"),
         ("k_tower_fp8@8192", "pmc_fp8", "k_tower_fp8", {"positions_per_launch": 8192}, "python3 tools/bench_net.py 8192 60 fp8"),
+        ("k_tower_fp8@selfplay", "pmc_cfg5sp", "k_tower_fp8", None,
+         "python3 bench.py --precision fp8 --games 8192 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary (two pipelines of 4096 games)"),
         ("k_reversi_step", "pmc_env", "k_reversi_step", {"games": 1 << 26}, "python3 tools/bench_env.py")):
     suffix = "_gw4" if name == "pmc_ttt" else ""
     f, w = mean(f"{name}_fetch{suffix}", "FETCH_SIZE", kern), mean(f"{name}_write{suffix}", "WRITE_SIZE", kern)
@@ -48,9 +50,9 @@ for key, name, kern, shape, cmd in (
            "hbm_bytes_per_launch_uncorrected": int((f[0] + w[0]) * 1024), "launches": f[1], "command": cmd}
     if shape:
         ent.update(shape)
-    if key == "k_tower_bf16":
+    if key in ("k_tower_bf16", "k_tower_fp8@selfplay"):
         try:  # positions per launch of the very run the counters come from
-            d = json.load(open(os.path.join(src, f"{tag}_pmc_bench_fetch.json")))
+            d = json.load(open(os.path.join(src, f"{tag}_{name}_fetch.json")))
             ent["positions_per_launch"] = d["roofline"]["positions_per_launch"]
         except Exception:
             pass

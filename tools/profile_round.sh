@@ -32,6 +32,11 @@ if has pmc_bench; then
   run 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_bench_fetch" -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_bench_fetch.json" 2> "$OUT/pmc_bench_fetch.err"
   run 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_bench_write" -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_bench_write.json" 2> "$OUT/pmc_bench_write.err"
 fi
+if has pmc_cfg5sp; then
+  # secondary.cfg5_selfplay's shape: the fp8 tower as the in-loop evaluator of 8192 games (two pipelines of 4096), counters per launch
+  run 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_cfg5sp_fetch" -o t -- python3 bench.py --precision fp8 --games 8192 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_cfg5sp_fetch.json" 2> "$OUT/pmc_cfg5sp_fetch.err"
+  run 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_cfg5sp_write" -o t -- python3 bench.py --precision fp8 --games 8192 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_cfg5sp_write.json" 2> "$OUT/pmc_cfg5sp_write.err"
+fi
 if has pmc_ttt; then
   for gw in 4 0; do   # 4 = the TTT-specialised fused search at its default lanes (cfg 2 as bench.py runs it), 0 = the generic fused kernel (--ttt-lanes -1)
     if [ $gw = 0 ]; then LANES="--ttt-lanes -1"; else LANES="--ttt-lanes $gw"; fi
