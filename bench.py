@@ -18,8 +18,10 @@ every step completes ~B/58 games and value = games completed in the timed
 region / time.  No work is skipped: every move of every game does all 800
 simulations and every distinct non-terminal position of a search goes through the
 full net.  (A position that a search reaches a second time by another move order --
-6-12 % of a search's leaves -- shares the evaluation of its first occurrence: the
-engine's evaluation cache, BZ_ENGINE_EVAL_CACHE.  Results are bit for bit those
+6-12 % of a search's leaves -- or that the slot's PREVIOUS search already evaluated --
+the played move's old subtree, a quarter of the previous search -- shares that
+evaluation: the engine's evaluation cache, BZ_ENGINE_EVAL_CACHE(_CARRY).  The tree is
+still built from scratch for every move.  Results are bit for bit those
 without it, the tree is the same tree; `roofline` counts only the rows the net
 really computed, the line says how many evaluations were shared, and
 `secondary.cfg3_no_eval_cache` / `--no-eval-cache` run the same workload with every
@@ -729,10 +731,12 @@ def run_reversi(ctx, args, B, sims, K, W):
            "config": {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{prec}",
                       "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8, "openings": 12,
                       "evaluator": "policy/value conv tower 6x128 (226.86 MFLOP per leaf), random init seed 0",
-                      "evaluation_cache": ({"on": True, "evaluations_shared": cnt["n_cache_hits"], "evaluations_computed": cnt["n_net_leaves"],
+                      "evaluation_cache": ({"on": True, "evaluations_shared": cnt["n_cache_hits"],
+                                            "of_which_from_the_previous_search": cnt["n_cache_hits_prev"], "evaluations_computed": cnt["n_net_leaves"],
                                             "shared_fraction": cnt["n_cache_hits"] / max(1, cnt["n_cache_hits"] + cnt["n_net_leaves"]),
-                                            "note": "a position met again inside ONE search takes its first evaluation (bit-identical "
-                                                    "results, tests/test_gpu_parity.py); roofline / net_evals_per_s count computed rows only"}
+                                            "note": "a position met again inside one search, or evaluated by the slot's previous search (after a move the "
+                                                    "played child's old subtree is re-created node for node), takes that evaluation: bit-identical "
+                                                    "results (tests/test_gpu_parity.py); roofline / net_evals_per_s count computed rows only"}
                                            if not args.no_eval_cache else {"on": False}),
                       "step": "one move for all concurrent games (steady-state pool, staggered starts)"
                       if args.mode == "steady" else "one complete self-play iteration (all games, start to end)",

@@ -16,9 +16,10 @@ ST_RUNNING, ST_TERMINAL, ST_ILLEGAL, ST_MUST_PASS = range(4)
 PASS_ACTION = 64
 ENGINE_REUSE_SUBTREE = 1
 ENGINE_EVAL_CACHE = 2   # BZ_ENGINE_EVAL_CACHE: a position met again inside one search shares its first evaluation
+ENGINE_EVAL_CACHE_CARRY = 4   # BZ_ENGINE_EVAL_CACHE_CARRY: ... and the previous search's evaluations serve the next search too
 PROF_SLOTS = ("tower", "stem", "heads", "select", "expand_backup", "search_fused", "play", "env_step")
 COUNTER_NAMES = ("n_sims", "n_path_nodes", "n_child_scored", "n_edges_backed", "n_expanded",
-                 "n_child_written", "n_env_steps", "n_net_leaves", "n_cache_hits")
+                 "n_child_written", "n_env_steps", "n_net_leaves", "n_cache_hits", "n_cache_hits_prev")
 
 u64, u32, i32, i64, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_int64, C.c_void_p
 

@@ -62,7 +62,7 @@ constexpr u32 kTerm = 1u << 8;
 // from that node instead of going through the evaluator again
 enum { LEAF_NONE = 0, LEAF_EVAL = 1, LEAF_TERMINAL = 2, LEAF_READY = 3, LEAF_COPY = 4 };
 enum { CNT_SIMS, CNT_PATH_NODES, CNT_CHILD_SCORED, CNT_EDGES_BACKED, CNT_EXPANDED, CNT_CHILD_WRITTEN,
-       CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_CACHE_HITS, CNT_N };
+       CNT_ENV_STEPS, CNT_NET_LEAVES, CNT_CACHE_HITS, CNT_CACHE_HITS_PREV, CNT_N };
 constexpr int kCntWords = 24;  // u64 words of the counters block: CNT_N work counters, then (diagnostic builds) stamps at 16..23
 // NEVAL[2]: packed-leaf counters, double-buffered by simulation parity (the tree step that
 // packs into one buffer zeroes the other, so no extra reset launch is needed)
@@ -79,8 +79,12 @@ struct __attribute__((aligned(64))) GameHot {
     u64 leaf_legal; u32 leaf_node, leaf_info;   // the leaf awaiting expansion / backup: its legal mask, node id, header
     u32 depth, n_nodes, n_edges, leaf_slot;     // its depth; the tree's fill; the evaluator row of the leaf
     u32 root_n, root_base;                      // the root's child count; visits a kept subtree came with (subtree reuse)
-    u32 tt_gen, copy_src, copy_e0, pad[3];      // evaluation cache: this search's generation; a COPY leaf's source node, its first edge
+    // evaluation cache: this search's generation; a COPY leaf's source node (bit 31: it lives in the PREVIOUS search's arena)
+    // and that node's first edge; the generation of the last search this slot took part in and how many nodes the
+    // previous search's arena holds for it (0: nothing to carry over)
+    u32 tt_gen, copy_src, copy_e0, last_gen, prev_nodes, pad[1];
 };
+constexpr u32 kSrcPrev = 1u << 31;
 static_assert(sizeof(GameHot) == 64, "layout");
 
 struct EngineDev {
@@ -102,7 +106,9 @@ struct EngineDev {
     int32_t* pack_off;  // [rounds][B]: first row of a finished game in the packed example block (k_pack_scan)
     // evaluation cache (BZ_ENGINE_EVAL_CACHE, net evaluators): per game a hash table position -> node of its first
     // evaluation in the current search (tt_buckets buckets of 16 eight-byte entries) and every node's value
-    int ecache, tt_buckets; u64* tt; float* node_v;
+    // ecache == 2 (BZ_ENGINE_EVAL_CACHE_CARRY): the previous search's tree stays intact in the other arena (nodes_alt / edges_alt
+    // / node_v_alt: the arenas alternate search by search) and its evaluations serve this search too
+    int ecache, tt_buckets; u64* tt; float *node_v, *node_v_alt;
 };
 
 struct Cnt { u32 v[CNT_N]; };
@@ -324,7 +330,7 @@ struct CoopChild<G, true> {
 
 // what the walk starts from: the root's position, mover colour and child count (its edges start at index 0)
 // `pre`: this lane's root edge (index sub) when the caller fetched the first kGW root edges ahead of the walk
-struct RootRef { u64 own, opp; int tm; int n; u32 sumN; bool has_pre; Edge pre; u32 tt_gen; };
+struct RootRef { u64 own, opp; int tm; int n; u32 sumN; bool has_pre; Edge pre; u32 tt_gen, prev_nodes; };
 // the node select created (valid when a child was created); src / src_e0: the node whose evaluation a COPY leaf shares
 struct LeafPos { u64 own, opp, legal; u32 info, src, src_e0; };
 
@@ -345,36 +351,44 @@ __device__ __forceinline__ u32 group_min_u32(u32 x) {
     if (kGW > 8) { const u32 y = xchg<8>(x); x = y < x ? y : x; }
     return x;
 }
-// looks (own, opp) up; a confirmed hit returns true with the source node and its first edge; a miss inserts `new_id`
-// (nodes 0 .. n_before - 1 exist and are expanded).  All lanes of the group return the same values.
+// looks (own, opp) up.  A confirmed hit returns true with the source node -- flagged kSrcPrev when it is a node of the
+// PREVIOUS search's tree (carry-over: generation gen - 1, arena nodes_alt, only ids below prev_nodes) -- and its first edge.
+// A miss, and a carry-over hit too, inserts `new_id` for this generation (nodes 0 .. new_id - 1 of this search exist and are
+// expanded; the new node will be by the time anyone finds it).  All lanes of the group return the same values.
 template <int kGW>
-__device__ __forceinline__ bool tt_lookup_insert(const EngineDev& E, int g, int sub, const Node* nodes, u64 own, u64 opp, u32 gen,
-                                                 u32 n_before, u32 new_id, u32& src, u32& src_e0) {
+__device__ __forceinline__ bool tt_lookup_insert(const EngineDev& E, int g, int sub, u64 own, u64 opp, u32 gen, u32 prev_nodes,
+                                                 u32 new_id, u32& src, u32& src_e0) {
     const u64 h = hash_pos(own, opp);
     const u32 tag = (u32)(h >> 32);
+    const u32 gen_prev = gen == 1u ? kTtGenMax - 1u : gen - 1u;  // (the host's counter cycles 1 .. 2^19 - 2)
     u64* bucket = E.tt + ((size_t)g * (size_t)E.tt_buckets + (size_t)(h & (u64)(E.tt_buckets - 1))) * 16;
-    u32 hit = ~0u, fre = ~0u;  // (slot << 16 | node) of the first matching / first free slot this lane saw
+    // (is-previous << 20 | slot << 16 | node) of the best matching slot this lane saw: this search's entries win
+    u32 hit = ~0u, fre = ~0u;
 #pragma unroll
     for (int s0 = 0; s0 < 16; s0 += kGW) {
         const int s = s0 + sub;
         const u64 e = bucket[s];
-        const u32 meta = (u32)(e >> 32);
-        const bool cur = (meta >> kChildBits) == gen;
-        if (cur && (u32)e == tag && hit == ~0u) hit = ((u32)s << 16) | (meta & kChildMask);
-        if (!cur && fre == ~0u) fre = (u32)s << 16;
+        const u32 meta = (u32)(e >> 32), egen = meta >> kChildBits;
+        const bool cur = egen == gen, prv = prev_nodes != 0u && egen == gen_prev;
+        if ((cur || prv) && (u32)e == tag) {
+            const u32 key = ((prv ? 1u : 0u) << 20) | ((u32)s << 16) | (meta & kChildMask);
+            hit = key < hit ? key : hit;
+        }
+        if (!cur && !prv && fre == ~0u) fre = (u32)s << 16;
     }
     hit = group_min_u32<kGW>(hit);
     fre = group_min_u32<kGW>(fre);
-    bool found = false;
+    bool found = false, from_prev = false;
     if (hit != ~0u) {
         const u32 x = hit & kChildMask;
-        if (x != 0u && x < n_before) {
-            const Node xn = nodes[x];  // (one address for the whole group)
+        from_prev = (hit >> 20) != 0u;
+        if (x != 0u && x < (from_prev ? prev_nodes : new_id)) {
+            const Node xn = (from_prev ? E.nodes_alt : E.nodes)[(size_t)g * E.ncap + x];  // (one address for the whole group)
             found = xn.own == own && xn.opp == opp && !(xn.info & kTerm) && (xn.info & 0xFFu) != 0u;
-            src = x; src_e0 = xn.edge0;
+            src = x | (from_prev ? kSrcPrev : 0u); src_e0 = xn.edge0;
         }
     }
-    if (!found && fre != ~0u) {
+    if ((!found || from_prev) && fre != ~0u) {
         const int s = (int)(fre >> 16);
         if (sub == s % kGW) bucket[s] = (u64)tag | ((u64)((gen << kChildBits) | new_id) << 32);
     }
@@ -460,7 +474,7 @@ __device__ __forceinline__ void dev_select(const EngineDev& E, int g, int sub, c
         leaf = id; kind = term ? LEAF_TERMINAL : LEAF_EVAL; tval = (float)tv;
         if (E.ecache && !term) {  // evaluated before in this search? (wave-uniform branch: a kernel argument)
             u32 src = 0, src_e0 = 0;
-            if (tt_lookup_insert<kGW>(E, g, sub, nodes, cown, copp, root.tt_gen, id, id, src, src_e0)) { kind = LEAF_COPY; lp.src = src; lp.src_e0 = src_e0; }
+            if (tt_lookup_insert<kGW>(E, g, sub, cown, copp, root.tt_gen, root.prev_nodes, id, src, src_e0)) { kind = LEAF_COPY; lp.src = src; lp.src_e0 = src_e0; }
         }
         st.mark(4);
         break;
@@ -573,12 +587,12 @@ __device__ __forceinline__ int dev_expand(const EngineDev& E, int g, int sub, u3
 // N = 0, W = 0, no child.  legal / info as for dev_expand.  Returns the number of edges written.
 template <class G, int kGW = G::GW>
 __device__ __forceinline__ int dev_expand_copy(const EngineDev& E, int g, int sub, u32 leaf, u64 legal, u32 info, u32 src_e0,
-                                               u32& n_edges_g, Cnt& c) {
+                                               bool from_prev, u32& n_edges_g, Cnt& c) {
     constexpr int kCH = (G::MAXCH + kGW - 1) / kGW;
     Node* nd = E.nodes + (size_t)g * E.ncap + leaf;
     const u32 e0 = n_edges_g;
     Edge* ed = E.edges + (size_t)g * E.ecap + e0;
-    const Edge* from = E.edges + (size_t)g * E.ecap + src_e0;
+    const Edge* from = (from_prev ? E.edges_alt : E.edges) + (size_t)g * E.ecap + src_e0;
     const int room = E.ecap - (int)e0;
     int n = legal == 0 ? 1 : popc64(legal);
     if (n > room) { if (sub == 0) atomicOr(&E.flags[FLAG_ERR], ERR_EDGE_OVERFLOW); n = room; }
@@ -592,6 +606,7 @@ __device__ __forceinline__ int dev_expand_copy(const EngineDev& E, int g, int su
         c.v[CNT_EXPANDED]++;
         c.v[CNT_CHILD_WRITTEN] += (u32)n;
         c.v[CNT_CACHE_HITS]++;
+        if (from_prev) c.v[CNT_CACHE_HITS_PREV]++;
     }
     n_edges_g = e0 + (u32)n;
     return n;
@@ -752,7 +767,14 @@ __global__ void __launch_bounds__(256) k_root_begin(EngineDev E, u32 tt_gen) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     uint8_t kind = LEAF_NONE;
-    E.hot[g].tt_gen = tt_gen;  // entries of earlier searches in the evaluation cache are free slots from now on
+    if (E.ecache) {  // entries older than the previous search are free slots from now on
+        const u32 gen_prev = tt_gen == 1u ? kTtGenMax - 1u : tt_gen - 1u;
+        // carry-over: the other arena holds this slot's previous tree only if the slot took part in the previous search
+        const bool carry = E.ecache == 2 && E.hot[g].last_gen == gen_prev;
+        E.hot[g].prev_nodes = carry ? E.hot[g].n_nodes : 0u;
+        E.hot[g].tt_gen = tt_gen;
+        if (E.g_state[g] == 0) E.hot[g].last_gen = tt_gen;
+    }
     const u32 keep = (E.reuse && E.g_state[g] == 0) ? E.g_reuse[g] : 0u;
     if (keep) {
         dev_reroot<G>(E, g, keep);
@@ -863,8 +885,9 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 }
                 if (leaf == 0) { root_n = n; pre_ok = false; }  // the root's edges did not exist when re0 was fetched
             } else if (kind == LEAF_COPY) {  // ---- round trip 2: the first evaluation's edges and value (evaluation cache)
-                v = E.node_v[(size_t)g * E.ncap + hot.copy_src];
-                n = dev_expand_copy<G>(E, g, sub, leaf, nlegal, ninfo, hot.copy_e0, ne, c);
+                const bool from_prev = (hot.copy_src & kSrcPrev) != 0u;
+                v = (from_prev ? E.node_v_alt : E.node_v)[(size_t)g * E.ncap + (hot.copy_src & ~kSrcPrev)];
+                n = dev_expand_copy<G>(E, g, sub, leaf, nlegal, ninfo, hot.copy_e0, from_prev, ne, c);
                 if (sub == 0) { E.hot[g].n_edges = ne; E.node_v[(size_t)g * E.ncap + leaf] = v; }
             } else {
                 v = (float)((int)((ninfo >> 9) & 3u) - 1);
@@ -893,7 +916,7 @@ __global__ void __launch_bounds__(256) k_tree_step(EngineDev E, int do_expand, i
                 u32 leaf2; int k2, depth; float tv;
                 LeafPos lpos; lpos.own = 0; lpos.opp = 0; lpos.legal = 0; lpos.info = 0; lpos.src = 0; lpos.src_e0 = 0;
                 RootRef root; root.own = rown; root.opp = ropp; root.tm = rtm; root.n = root_n;
-                root.sumN = sim_idx + root_base; root.has_pre = pre_ok; root.pre = re0; root.tt_gen = hot.tt_gen;
+                root.sumN = sim_idx + root_base; root.has_pre = pre_ok; root.pre = re0; root.tt_gen = hot.tt_gen; root.prev_nodes = hot.prev_nodes;
                 PathHbm<kGW> sink; sink.p = path; sink.mine.eidx = 0; sink.mine.w0 = 0; sink.mine.W = 0.0f; sink.mine.pad = 0;
                 dev_select<G>(E, g, sub, root, nn, leaf2, k2, depth, tv, c, sink, lpos, st);  // ---- one round trip per level
                 sink.flush(sub, depth);
@@ -1373,7 +1396,7 @@ struct Carver {
 struct Offsets {
     int64_t nodes, edges, nodes_alt, edges_alt, g_reuse, g_own, g_opp, g_to_move, g_state, g_moves, g_nex, g_round, g_passes, hot,
         path, leaf_kind, leaf_own, leaf_opp, c_own, c_opp, logits, value, ex_own, ex_opp, ex_pi, ex_z, ex_mover,
-        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, pack_off, tt, node_v, total;
+        ex_act, ex_len, ex_winner, ex_meta, root_N, root_W, root_P, counters, cnt_slots, flags, pack_off, tt, node_v, node_v_alt, total;
     int n_cnt_slots;
     int ncap, ecap, na, maxd;
     int ecache, tt_buckets;
@@ -1408,8 +1431,12 @@ Offsets carve(const bz_engine_cfg& c) {
     Carver k;
     o.nodes = k.take(B * o.ncap * (int64_t)sizeof(Node));
     o.edges = k.take(B * o.ecap * (int64_t)sizeof(Edge));
-    o.nodes_alt = k.take(reuse ? B * o.ncap * (int64_t)sizeof(Node) : 0);
-    o.edges_alt = k.take(reuse ? B * o.ecap * (int64_t)sizeof(Edge) : 0);
+    // evaluation cache: net evaluators only (a synthetic evaluation costs less than the lookup), not with subtree reuse
+    // (a kept subtree's nodes are not in the new search's table).  2 = with carry-over: a second arena, like subtree reuse
+    o.ecache = ((c.flags & BZ_ENGINE_EVAL_CACHE) && net_eval(c.eval_kind) && !reuse) ? ((c.flags & BZ_ENGINE_EVAL_CACHE_CARRY) ? 2 : 1) : 0;
+    const bool two = reuse || o.ecache == 2;
+    o.nodes_alt = k.take(two ? B * o.ncap * (int64_t)sizeof(Node) : 0);
+    o.edges_alt = k.take(two ? B * o.ecap * (int64_t)sizeof(Edge) : 0);
     o.g_reuse = k.take(reuse ? B * 4 : 0);
     o.g_own = k.take(B * 8); o.g_opp = k.take(B * 8); o.g_to_move = k.take(B); o.g_state = k.take(B);
     o.g_moves = k.take(B * 4); o.g_nex = k.take(B * 4); o.g_round = k.take(B * 4); o.g_passes = k.take(B * 4);
@@ -1429,13 +1456,12 @@ Offsets carve(const bz_engine_cfg& c) {
     o.cnt_slots = k.take((int64_t)o.n_cnt_slots * CNT_N * 8);
     o.flags = k.take(FLAG_N * 4);
     o.pack_off = k.take(R * B * 4);
-    // evaluation cache: net evaluators only (a synthetic evaluation costs less than the lookup), not with subtree reuse
-    // (a kept subtree's nodes are not in the new search's table).  Buckets: a power of two, >= 2 slots per node
-    o.ecache = ((c.flags & BZ_ENGINE_EVAL_CACHE) && net_eval(c.eval_kind) && !reuse) ? 1 : 0;
+    // the table's buckets: a power of two, >= 2 slots per live node (with carry-over two searches' entries are live)
     o.tt_buckets = 16;
-    while ((int64_t)o.tt_buckets * 16 < 2 * (int64_t)o.ncap) o.tt_buckets *= 2;
+    while ((int64_t)o.tt_buckets * 16 < (o.ecache == 2 ? 4 : 2) * (int64_t)o.ncap) o.tt_buckets *= 2;
     o.tt = k.take(o.ecache ? B * o.tt_buckets * 16 * 8 : 0);
     o.node_v = k.take(o.ecache ? B * o.ncap * 4 : 0);
+    o.node_v_alt = k.take(o.ecache == 2 ? B * o.ncap * 4 : 0);
     o.total = k.off;
     return o;
 }
@@ -1500,7 +1526,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     d.leaf_own = at<u64>(ws, o.leaf_own); d.leaf_opp = at<u64>(ws, o.leaf_opp);
     d.c_own = at<u64>(ws, o.c_own); d.c_opp = at<u64>(ws, o.c_opp);
     d.compact = net_eval(cfg->eval_kind) ? 1 : 0;
-    d.ecache = o.ecache; d.tt_buckets = o.tt_buckets; d.tt = at<u64>(ws, o.tt); d.node_v = at<float>(ws, o.node_v);
+    d.ecache = o.ecache; d.tt_buckets = o.tt_buckets; d.tt = at<u64>(ws, o.tt); d.node_v = at<float>(ws, o.node_v); d.node_v_alt = at<float>(ws, o.node_v_alt);
     if (o.ecache) {  // generation 0 = never written
         hipError_t ce = hipMemset(d.tt, 0, (size_t)cfg->n_games * o.tt_buckets * 16 * 8);
         if (ce != hipSuccess) { delete e; return hip_fail(ce, "bz_engine_create: evaluation-cache clear"); }
@@ -1584,6 +1610,11 @@ BZ_EXPORT int32_t bz_engine_set_roots(bz_engine* e, const uint64_t* own, const u
 BZ_EXPORT int32_t bz_engine_root_begin(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     e->search_seq = e->search_seq % (kTtGenMax - 1u) + 1u;  // 1 .. 2^19 - 2 (0 = never written)
+    if (e->dev.ecache == 2) {  // the tree just searched stays intact in the other arena while the new one grows in this one
+        Node* tn = e->dev.nodes; e->dev.nodes = e->dev.nodes_alt; e->dev.nodes_alt = tn;
+        Edge* te = e->dev.edges; e->dev.edges = e->dev.edges_alt; e->dev.edges_alt = te;
+        float* tv = e->dev.node_v; e->dev.node_v = e->dev.node_v_alt; e->dev.node_v_alt = tv;
+    }
     BZ_DISPATCH(e, k_root_begin, stream, e->dev, e->search_seq);
     e->pack_parity = 1;
     return BZ_OK;

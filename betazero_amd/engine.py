@@ -116,9 +116,12 @@ class SelfPlayEngine:
                  seed=0, rounds=1, game_id_base=0, game_id_stride=None, device="cuda:0", stagger=0,
                  dirichlet_alpha=0.0, dirichlet_eps=0.0, reuse_subtree=False, ttt_lanes=0, eval_cache=True):
         """eval_cache (BZ_ENGINE_EVAL_CACHE, bz_abi.h): with a net evaluator, a leaf whose position was evaluated earlier in
-        the same search shares that evaluation instead of running the net again.  Every result is bit for bit what it is
-        without the cache (the net is a function of the position); counters()["n_cache_hits"] says how often it fired.
-        Ignored for the synthetic / external evaluators and with reuse_subtree."""
+        the same search shares that evaluation instead of running the net again; True / "carry" (the default) also takes
+        evaluations from the slot's PREVIOUS search (BZ_ENGINE_EVAL_CACHE_CARRY: after a move, the played child's old subtree
+        is re-created node for node by the new search), "search" only from the same search, False none.  Every result is bit
+        for bit what it is without the cache (the net is a function of the position); counters()["n_cache_hits"] (of which
+        "n_cache_hits_prev" from the previous search) says how often it fired.  Ignored for the synthetic / external
+        evaluators and with reuse_subtree."""
         check_sims(sims, reuse_subtree)
         _lib.require_gpu()
         L = _lib.lib()
@@ -128,7 +131,8 @@ class SelfPlayEngine:
         t_max = 9 if self.game == GAME_TTT else 64
         self.cfg = EngineCfg(self.game, n_games, sims, _EVALS[evaluator], c_puct, temp_moves, openings, rounds, t_max,
                              stagger, seed, game_id_base, n_games if game_id_stride is None else game_id_stride,
-                             (_lib.ENGINE_REUSE_SUBTREE if reuse_subtree else 0) | (_lib.ENGINE_EVAL_CACHE if eval_cache else 0),
+                             (_lib.ENGINE_REUSE_SUBTREE if reuse_subtree else 0) | (_lib.ENGINE_EVAL_CACHE if eval_cache else 0) |
+                             (_lib.ENGINE_EVAL_CACHE_CARRY if eval_cache in (True, "carry") else 0),
                              dirichlet_alpha, dirichlet_eps, ttt_lanes)
         nbytes = L.bz_engine_workspace_bytes(C.byref(self.cfg))
         if nbytes < 0:

@@ -236,6 +236,14 @@ typedef struct bz_engine_cfg {
  * say how often: counters[8] = repeats served from the cache, counters[7] = rows the evaluator computed; their sum is
  * what counters[7] reads without the cache.  A table hit is confirmed against the stored node's position before use. */
 #define BZ_ENGINE_EVAL_CACHE 2u
+/* ... and across CONSECUTIVE searches of a slot (with BZ_ENGINE_EVAL_CACHE): the previous search's tree stays intact in a
+ * second arena while the new one grows (the arenas alternate), and a leaf whose position that tree evaluated takes the
+ * evaluation from there.  After a move the new root is a child of the old one, and a fresh search from it re-creates that
+ * child's old subtree node for node (deterministic PUCT on the same evaluations), so about the played move's share of the
+ * previous search's visits -- a quarter at cfg 3 -- never reaches the net again.  The new tree is still built from scratch
+ * (this is NOT subtree reuse: no statistic is kept, DESIGN.md 3.10 stays an option of its own): results are bit for bit
+ * those without any cache.  counters[9] = the part of counters[8] that came from the previous search. */
+#define BZ_ENGINE_EVAL_CACHE_CARRY 4u
 
 /* offsets (bytes, from the workspace base) of the caller-visible arrays */
 typedef struct bz_engine_layout {

@@ -188,7 +188,7 @@ def _counters(cnt):
     """the oracle's 8 work counters under the engine's names; the oracle has no evaluation cache (every leaf is evaluated),
     so the engine's ninth counter reads 0 here"""
     d = dict(zip(COUNTER_NAMES, (int(c) for c in cnt)))
-    d["n_cache_hits"] = 0
+    d["n_cache_hits"] = d["n_cache_hits_prev"] = 0
     return d
 
 

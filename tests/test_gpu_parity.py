@@ -1100,12 +1100,15 @@ def test_cfg3_full_size_4096_games_800_sims_bf16_net_invariants(ev, B, stagger):
 @pytest.mark.parametrize("ev,game,B,sims", [("net_bf16", "reversi", 384, 800), ("net_f32", "reversi6", 40, 300), ("net_fp8", "reversi", 300, 200)],
                          ids=["bf16_800", "f32_6x6_300", "fp8_200"])
 def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, sims):
-    """BZ_ENGINE_EVAL_CACHE: a leaf whose position was evaluated earlier in the same search takes that node's priors and
-    value instead of an evaluator row.  Against the SAME engine without the cache, from all game phases (staggered
-    pool) and over two moves: root N / W / P of every game bit for bit, the played moves and the example rows bit for bit,
-    every work counter equal -- except that the evaluator computed fewer rows: n_net_leaves(on) + n_cache_hits ==
-    n_net_leaves(off), with hits > 3 % (the CPU measurement on the oracle, profiles/r05_leaf_duplication.json: 6 - 12 %).
-    (That the cache-ON engine equals the ORACLE, which has no cache, is what every net-evaluator parity test checks.)"""
+    """BZ_ENGINE_EVAL_CACHE (+ _CARRY): a leaf whose position was evaluated earlier in the same search -- or, with carry-over,
+    in the slot's previous search -- takes that node's priors and value instead of an evaluator row.  Three engines on the
+    same games (cache with carry-over = the default, cache inside a search only, no cache), from all game phases (staggered
+    pool) and over three moves: root N / W / P of every game bit for bit, the played moves and the example rows bit for bit,
+    every work counter equal -- except that the evaluator computed fewer rows: n_net_leaves + n_cache_hits is the same in
+    all three, with in-search hits > 3 % at 800 simulations (the CPU measurement on the oracle,
+    profiles/r05_leaf_duplication.json: 6 - 12 %) and carried-over hits on top from the second move on (about the played
+    move's share of the previous search's visits).  (That the cache-ON engine equals the ORACLE, which has no cache, is what
+    every net-evaluator parity test checks.)"""
     from betazero_amd.net import DeviceNet
     mod = _net(128, 6, bf16=True) if ev != "net_f32" else _net(32, 2, seed=3)
     if ev == "net_fp8":
@@ -1113,29 +1116,36 @@ def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, s
         fake_quantize_fp8_(mod)
     dn = DeviceNet.from_module(mod, B)
     kw = dict(net=dn, temp_moves=8, openings=1, seed=2, rounds=2, stagger=58 if game == "reversi" else 20)
-    on, off = _engine(game, B, sims, ev, eval_cache=True, **kw), _engine(game, B, sims, ev, eval_cache=False, **kw)
-    for e in (on, off):
+    engs = [_engine(game, B, sims, ev, eval_cache=mode, **kw) for mode in (True, "search", False)]
+    for e in engs:
         e.reset_games(); e.reset_counters()
-    for mv in range(2):
-        for e in (on, off):
+    for mv in range(3):
+        for e in engs:
             e.search()
-        (N1, W1, P1), (N0, W0, P0) = on.root_stats(), off.root_stats()
-        assert np.array_equal(N1, N0) and np.array_equal(W1.view(np.uint32), W0.view(np.uint32)) and np.array_equal(P1.view(np.uint32), P0.view(np.uint32)), mv
-        for e in (on, off):
+        N0, W0, P0 = engs[2].root_stats()
+        for e in engs[:2]:
+            N1, W1, P1 = e.root_stats()
+            assert np.array_equal(N1, N0) and np.array_equal(W1.view(np.uint32), W0.view(np.uint32)) and np.array_equal(P1.view(np.uint32), P0.view(np.uint32)), mv
+        for e in engs:
             e.play(True)
-    assert on.status() == off.status()
-    a, b = on.example_tensors(), off.example_tensors()
-    for f in ("own", "opp", "act", "mover", "len"):
-        assert torch.equal(a[f], b[f]), f
-    assert torch.equal(a["pi"].view(torch.int32), b["pi"].view(torch.int32))
-    c1, c0 = on.counters(), off.counters()
-    for k in c1:
-        if k not in ("n_net_leaves", "n_cache_hits"):
-            assert c1[k] == c0[k], (k, c1[k], c0[k])
-    assert c0["n_cache_hits"] == 0 and c1["n_net_leaves"] + c1["n_cache_hits"] == c0["n_net_leaves"]
-    frac = c1["n_cache_hits"] / c0["n_net_leaves"]
-    print(f"evaluation cache, {ev} {game} {B} games x {sims} sims: {c1['n_cache_hits']} of {c0['n_net_leaves']} evaluations shared = {frac:.3f}")
-    assert frac > (0.03 if sims >= 300 else 0.01)   # (a 200-simulation tree meets fewer transpositions than an 800-simulation one)
+    assert engs[0].status() == engs[1].status() == engs[2].status()
+    b = engs[2].example_tensors()
+    for e in engs[:2]:
+        a = e.example_tensors()
+        for f in ("own", "opp", "act", "mover", "len"):
+            assert torch.equal(a[f], b[f]), f
+        assert torch.equal(a["pi"].view(torch.int32), b["pi"].view(torch.int32))
+    cc, cs, c0 = (e.counters() for e in engs)
+    for k in c0:
+        if k not in ("n_net_leaves", "n_cache_hits", "n_cache_hits_prev"):
+            assert cc[k] == cs[k] == c0[k], (k, cc[k], cs[k], c0[k])
+    assert c0["n_cache_hits"] == 0 and cs["n_cache_hits_prev"] == 0
+    assert cc["n_net_leaves"] + cc["n_cache_hits"] == cs["n_net_leaves"] + cs["n_cache_hits"] == c0["n_net_leaves"]
+    frac_s, frac_c = cs["n_cache_hits"] / c0["n_net_leaves"], cc["n_cache_hits"] / c0["n_net_leaves"]
+    print(f"evaluation cache, {ev} {game} {B} games x {sims} sims x 3 moves: inside a search {cs['n_cache_hits']} of {c0['n_net_leaves']} "
+          f"evaluations shared = {frac_s:.3f}; with carry-over {cc['n_cache_hits']} ({cc['n_cache_hits_prev']} from the previous search) = {frac_c:.3f}")
+    assert frac_s > (0.03 if sims >= 300 else 0.01)   # (a 200-simulation tree meets fewer transpositions than an 800-simulation one)
+    assert cc["n_cache_hits_prev"] > 0.05 * c0["n_net_leaves"] and frac_c > frac_s + 0.05
 
 
 def test_cfg3_800_sims_bf16_net_search_close_to_oracle_bf16_emulation():
