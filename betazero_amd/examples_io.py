@@ -1,7 +1,12 @@
 """On-disk example format compatible with the reference's CSV
 (src/tic_tac_toe/SL/generate_training_games.py:40-54 writes it, SL/train.py:16,38-40
 reads it): columns State,Action with space-joined integers.  save_examples_csv adds
-Pi and Z columns (ignored by the reference's reader, which only touches State/Action)."""
+Pi and Z columns (ignored by the reference's reader, which only touches State/Action).
+
+The CSV is the reference's format and fine at its size (180 rows); a self-play iteration at the headline configuration is
+~237,000 rows x 65 floats -- ~150 MB of text.  save_examples_npz / load_examples_npz are the format for that (SURVEY 8(f) row
+2 "or an .npz side-car"): the Examples arrays as they are (bitboards, pi, z, mover, act, game, ply), compressed, loaded
+back bit for bit; `states()` of the loaded object gives the reference's State column whenever it is wanted."""
 import csv
 
 import numpy as np
@@ -21,16 +26,36 @@ def save_to_csv(states, actions, filename="tic_tac_toe_data.csv"):
 def save_examples_csv(ex, filename):
     """Examples -> CSV readable by the reference's TicTacToeDataset (State, Action = one-hot of
     the move played) plus Pi (visit-count policy) and Z (outcome for the mover)."""
-    s = ex.states().reshape(len(ex), -1)
-    na = ex.pi.shape[1]
+    s = ex.states().reshape(len(ex), -1).astype(np.int64)
+    onehot = np.zeros_like(s)
+    on_board = np.asarray(ex.act) < s.shape[1]              # (Reversi's pass, action 64, has no cell)
+    onehot[np.nonzero(on_board)[0], np.asarray(ex.act)[on_board]] = 1
+    pi = np.asarray(ex.pi, dtype=np.float32)
+    # one str() per ELEMENT, not per row of Python-level joins: repr of a float32 (shortest text that reads back to the same
+    # float32) through numpy's own formatter, then one join per row
+    pis = np.array([np.format_float_positional(v, unique=True, trim="0") if np.isfinite(v) else repr(float(v)) for v in pi.reshape(-1)],
+                   dtype=object).reshape(pi.shape)
     with open(filename, "w", newline="") as f:
         f.write("State,Action,Pi,Z\n")
-        for i in range(len(ex)):
-            onehot = np.zeros(s.shape[1], dtype=np.int64)
-            if ex.act[i] < s.shape[1]:
-                onehot[ex.act[i]] = 1
-            f.write(" ".join(str(int(v)) for v in s[i]) + "," + " ".join(str(int(v)) for v in onehot) + "," +
-                    " ".join(repr(float(v)) for v in ex.pi[i][:na]) + "," + str(int(ex.z[i])) + "\n")
+        f.writelines(" ".join(map(str, s[i])) + "," + " ".join(map(str, onehot[i])) + "," + " ".join(pis[i]) + "," +
+                     str(int(ex.z[i])) + "\n" for i in range(len(ex)))
+
+
+_NPZ_FIELDS = ("own", "opp", "pi", "z", "mover", "act", "game", "ply")
+
+
+def save_examples_npz(ex, filename):
+    """Examples (host) or DeviceExamples -> one compressed .npz: the arrays as they are, plus the board size"""
+    if hasattr(ex, "cpu") and not isinstance(ex.own, np.ndarray):
+        ex = ex.cpu()
+    np.savez_compressed(filename, size=np.int64(ex.size), **{k: np.asarray(getattr(ex, k)) for k in _NPZ_FIELDS})
+
+
+def load_examples_npz(filename):
+    """-> Examples, bit for bit what save_examples_npz was given (no pickle involved)"""
+    from .engine import Examples
+    d = np.load(filename, allow_pickle=False)
+    return Examples(**{k: d[k] for k in _NPZ_FIELDS}, size=int(d["size"]))
 
 
 def load_csv(filename):

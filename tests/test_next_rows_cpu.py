@@ -144,3 +144,53 @@ def test_refresh_device_net_refuses_non_finite_weights():
         with pytest.raises(FloatingPointError, match="polfc.bias"):
             refresh_device_net(dn, m)
         assert not dn.updated
+
+
+def test_examples_npz_roundtrip_bit_for_bit_and_csv_floats_read_back_exactly(tmp_path):
+    """the .npz format for headline-sized example sets (SURVEY 8(f) row 2's side-car): every array bit for bit; and the CSV
+    writer's Pi text (shortest representation of each float32) reads back to the same float32"""
+    from betazero_amd.engine import Examples
+    from betazero_amd.examples_io import load_csv, load_examples_npz, save_examples_csv, save_examples_npz
+    rng = np.random.default_rng(3)
+    n = 200
+    own = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) | (np.uint64(1) << np.uint64(63))
+    opp = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64) & ~own
+    pi = (rng.random((n, 65)) ** 8).astype(np.float32)
+    pi[0] = 0.0; pi[0, 64] = 1.0; pi[1, 3] = np.float32(1e-30); pi[2, 5] = np.float32(1 / 3)
+    ex = Examples(own, opp, pi, rng.integers(-1, 2, n).astype(np.int8), rng.choice([-1, 1], n).astype(np.int8),
+                  rng.integers(0, 65, n).astype(np.uint8), rng.integers(0, 10**12, n), rng.integers(0, 60, n).astype(np.int32), 8)
+    p = tmp_path / "ex.npz"
+    save_examples_npz(ex, str(p))
+    back = load_examples_npz(str(p))
+    assert back.size == 8 and len(back) == n
+    for k in ("own", "opp", "z", "mover", "act", "game", "ply"):
+        assert np.array_equal(getattr(back, k), getattr(ex, k)) and getattr(back, k).dtype == getattr(ex, k).dtype, k
+    assert np.array_equal(back.pi.view(np.uint32), ex.pi.view(np.uint32))
+    c = tmp_path / "ex.csv"
+    save_examples_csv(ex, str(c))
+    rows = load_csv(str(c))
+    assert np.array_equal(rows["Pi"].view(np.uint32), ex.pi.view(np.uint32)) and np.array_equal(rows["Z"], ex.z)
+    assert np.array_equal(rows["State"], ex.states().reshape(n, 64))
+    passes = ex.act == 64
+    assert (rows["Action"][passes].sum(1) == 0).all() and np.array_equal(rows["Action"][~passes].argmax(1), ex.act[~passes])
+
+
+def test_holdout_split_is_the_reference_split():
+    """SL/train.py:66-76: val_size = int(total_size * validation_split), a random partition of the rows"""
+    import torch
+    from betazero_amd.engine import DeviceExamples, Examples
+    from betazero_amd.train import holdout_split, select_rows
+    g = torch.Generator().manual_seed(0)
+    for n, frac in ((180, 0.2), (7, 0.2), (1000, 0.25), (5, 0.0)):
+        tr, va = holdout_split(n, frac, g, "cpu")
+        assert len(va) == int(n * frac) and len(tr) == n - len(va)
+        assert sorted(torch.cat([tr, va]).tolist()) == list(range(n))
+    tr2, va2 = holdout_split(180, 0.2, torch.Generator().manual_seed(0), "cpu")
+    tr3, va3 = holdout_split(180, 0.2, torch.Generator().manual_seed(0), "cpu")
+    assert torch.equal(va2, va3) and not torch.equal(va2, torch.arange(36))       # seeded, and a real shuffle
+    n = 30
+    ex = DeviceExamples.from_host(Examples(np.arange(n, dtype=np.uint64), np.zeros(n, np.uint64), np.zeros((n, 9), np.float32),
+                                           np.zeros(n, np.int8), np.ones(n, np.int8), np.zeros(n, np.uint8), np.arange(n),
+                                           np.zeros(n, np.int32), 3), "cpu")
+    sub = select_rows(ex, va2[va2 < n])
+    assert sub.own.tolist() == va2[va2 < n].tolist() and sub.size == 3
