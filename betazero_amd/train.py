@@ -153,9 +153,11 @@ class GraphedTrainStep:
         # capture_autograd: a step that goes through torch autograd (step_kernels=False, or a module without the fused tower) is
         # NOT captured into a HIP graph unless asked for -- it runs eagerly, same arithmetic.  Captured autograd steps returned
         # wrong gradients once in a few hundred replays on this stack (a bias gradient of 6e32 at replay 305 / 306, an all-zero
-        # one at replay 702 / 703: profiles/r04_channels_last_cause.txt); the replay numbers repeat across seeds, so the cause
-        # is something deterministic that has not been found, and replacing the one reduction that was caught proves nothing
-        # about the others.  The all-kernel step (step_kernels) contains no torch kernel and is captured as before.
+        # one at replay 702 / 703: profiles/r04_channels_last_cause.txt).  Cause (profiles/r05_graph_memset_node.txt,
+        # tools/exp_graph_reduction.py): torch's multi-block reductions zero their semaphores with cudaMemsetAsync on the launch
+        # stream -- a memset NODE under capture -- and a captured memset node does not reliably zero its buffer on replay here
+        # (reproduced with the memset alone).  The all-kernel step (step_kernels) contains no memset node and no torch kernel
+        # and is captured as before.
         self.capture = self.step_plan is not None or bool(capture_autograd)
         self.own = torch.zeros(batch, dtype=torch.int64, device=self.dev)
         self.opp = torch.zeros(batch, dtype=torch.int64, device=self.dev)

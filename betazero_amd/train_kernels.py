@@ -120,9 +120,9 @@ class _RowsLinear(torch.autograd.Function):
         # the bias gradient the same way (x a column of ones) rather than as gy.sum(0): a 65,536-row column sum is a
         # multi-block torch reduction, and inside replayed HIP graphs such sums came back wrong once in a few hundred
         # steps on this stack (all zeros here; 6e32 in the stock channels-last path -- profiles/r04_channels_last_cause.txt)
-        # (the CAUSE is unproven: the failing replay numbers repeat across seeds, which points at something deterministic in the
-        # captured reduction's buffers rather than at random flakiness -- DESIGN.md 9; so GraphedTrainStep no longer captures
-        # the autograd forms of the step at all unless asked to, train.py)
+        # (the cause, found in round 5: that reduction zeroes its semaphores with a captured cudaMemsetAsync, and captured memset
+        # nodes do not reliably execute on replay on this stack -- profiles/r05_graph_memset_node.txt; GraphedTrainStep no
+        # longer captures the autograd forms of the step unless asked to, train.py)
         gb = torch.bmm(gyc, gy.new_ones((ch, rows // ch, 1))).sum(0, dtype=torch.float32).squeeze(1)
         return gx, gW.to(ctx.dts[1]), gb.to(ctx.dts[2])
 
