@@ -551,9 +551,9 @@ def run_env(ctx, n, K, W):
             "roofline": {"bound": "hbm", "kernel": "k_reversi_step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": 42.0 * n,
-                         "note": "bound by integer VALU issue, not HBM: 350 VALU instructions per step (8 x 15 carry-propagation "
-                                 "flips + ~150 legal mask + ~60 I/O and status) at 4 cycles per wave64 instruction keep the "
-                                 "VALU ~100 % busy (SQ_ACTIVE_INST_VALU, profiles/r03_pmc_env_sq_pmc.csv)"}}
+                         "note": "bound by vector-instruction issue, not HBM: 315 vector instructions per step (SQ_INSTS_VALU, "
+                                 "profiles/r05_pmc_env_sq_pmc.csv; ~98 flips by carry propagation + ~134 next legal mask + selects, status "
+                                 "and I/O) at 4 cycles per wave64 instruction; profiles/r05_env_isa.txt has the histogram"}}
 
 
 def run_ttt(ctx, B, sims, K, W, ttt_lanes=0):
