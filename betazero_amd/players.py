@@ -138,6 +138,9 @@ class MCTSPlayer(Player):
         return self._eng[game]
 
     def get_move(self, board):
+        if hasattr(board, "size") and board.size not in (8, 6, 4):
+            raise ValueError(f"the search engine plays Reversi on 8x8, 6x6 and 4x4 boards, not {board.size}x{board.size} "
+                             "(the rule calls of ReversiBoard cover every size)")
         game = {8: "reversi", 6: "reversi6", 4: "reversi4"}[board.size] if hasattr(board, "size") else "ttt"
         if game == "ttt" and self.evaluator.startswith("net"):
             raise ValueError("the conv net evaluators serve the Reversi boards; use evaluator='uniform' or 'hash' for tic-tac-toe")
