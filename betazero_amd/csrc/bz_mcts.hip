@@ -763,14 +763,14 @@ __device__ __forceinline__ void dev_reroot(const EngineDev& E, int g, u32 src_ro
 }
 
 template <class G>
-__global__ void __launch_bounds__(256) k_root_begin(EngineDev E, u32 tt_gen) {
+__global__ void __launch_bounds__(256) k_root_begin(EngineDev E, u32 tt_gen, int carry_ok) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.B) return;
     uint8_t kind = LEAF_NONE;
     if (E.ecache) {  // entries older than the previous search are free slots from now on
         const u32 gen_prev = tt_gen == 1u ? kTtGenMax - 1u : tt_gen - 1u;
         // carry-over: the other arena holds this slot's previous tree only if the slot took part in the previous search
-        const bool carry = E.ecache == 2 && E.hot[g].last_gen == gen_prev;
+        const bool carry = E.ecache == 2 && carry_ok && E.hot[g].last_gen == gen_prev;
         E.hot[g].prev_nodes = carry ? E.hot[g].n_nodes : 0u;
         E.hot[g].tt_gen = tt_gen;
         if (E.g_state[g] == 0) E.hot[g].last_gen = tt_gen;
@@ -1381,6 +1381,7 @@ struct bz_engine {
     int pack_parity;  // which NEVAL buffer the last root_begin / select packed into
     int ttt_gw;       // lanes per game of the TTT-specialised fused search (cfg.ttt_lanes; 0 = the generic any-game kernel)
     uint32_t search_seq;  // searches begun so far: the evaluation cache's generation (entries of earlier searches are dead)
+    uint64_t eval_epoch;  // bz_net_epoch of the weights the previous search evaluated with (carry-over needs the same ones)
     // bz_engines_step: ring of blocking-sync events that bounds how far the host thread runs ahead of this engine's
     // stream (created on first use)
     hipEvent_t ahead[4];
@@ -1504,7 +1505,7 @@ BZ_EXPORT int32_t bz_engine_create(const bz_engine_cfg* cfg, void* ws, int64_t b
     BZ_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "bz_engine_create: workspace must be 256-byte aligned");
     bz_engine* e = new (std::nothrow) bz_engine();
     if (!e) { set_error("out of host memory"); return BZ_ENOMEM; }
-    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1; e->n_ahead = 0; e->search_seq = 0;
+    e->cfg = *cfg; e->net = nullptr; e->bytes = o.total; e->pack_parity = 1; e->n_ahead = 0; e->search_seq = 0; e->eval_epoch = 0;
     // measured on MI355X at 65,536 games x 50 sims: round 2 (profiles/r02_bench_ttt_gw*) 2 lanes 0.185 ms, 4 lanes 0.190 ms,
     // 8 lanes 0.294 ms per launch; round 3, after the kernel became issue-bound and lost a third of its instructions
     // (profiles/r03_bench_ttt_lanes.txt): 1 lane 0.162, 2 lanes 0.137, 4 lanes 0.134, 8 lanes 0.181 ms -> 4 lanes
@@ -1615,7 +1616,12 @@ BZ_EXPORT int32_t bz_engine_root_begin(bz_engine* e, void* stream) {
         Edge* te = e->dev.edges; e->dev.edges = e->dev.edges_alt; e->dev.edges_alt = te;
         float* tv = e->dev.node_v; e->dev.node_v = e->dev.node_v_alt; e->dev.node_v_alt = tv;
     }
-    BZ_DISPATCH(e, k_root_begin, stream, e->dev, e->search_seq);
+    // evaluations of the previous search are this search's only under the same weights (bz_net_update / bz_engine_set_net between
+    // two searches of a live engine: nothing is carried over, exactly as if the slot had sat the previous search out)
+    const uint64_t epoch = bz_net_epoch(e->net);
+    const int carry_ok = epoch == e->eval_epoch;
+    e->eval_epoch = epoch;
+    BZ_DISPATCH(e, k_root_begin, stream, e->dev, e->search_seq, carry_ok);
     e->pack_parity = 1;
     return BZ_OK;
 }

@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <new>
+#include <atomic>
 #include <vector>
 
 #include "bz_common.h"
@@ -54,6 +55,9 @@ struct bz_net {
     // different streams are ordered through this event (the MFMA paths have no such scratch)
     hipEvent_t f32_done;
     bool f32_used;
+    // stamp of the parameter upload the weights came from, unique over all nets of the process: an engine's evaluation
+    // cache carries nothing over from a search made with another stamp
+    uint64_t epoch;
 };
 
 namespace {
@@ -840,7 +844,10 @@ template <class T> T* at(void* base, int64_t off) { return reinterpret_cast<T*>(
 }  // namespace
 
 // host repack of the flat torch-layout parameter vector into the kernels' layouts, one H2D copy
+static std::atomic<uint64_t> g_param_epoch{0};
+
 static int32_t upload_params(bz_net* n, const float* p, hipStream_t s) {
+    n->epoch = ++g_param_epoch;
     const int C = n->C, NB = n->NB, VH = n->VH;
     NetOffsets o = net_carve(C, NB, VH, n->max_batch);
     void* ws = n->ws_base;
@@ -1123,6 +1130,8 @@ static int32_t forward_bf16(bz_net* n, const uint64_t* own, const uint64_t* opp,
     BZ_LAUNCH_CHECK("k_tower_bf16");
     return BZ_OK;
 }
+
+uint64_t bz_net_epoch(const bz_net* n) { return n ? n->epoch : 0; }
 
 int32_t bz_net_forward_dev(bz_net* n, int bf16 /* 0 f32, 1 bf16, 2 fp8 */, const uint64_t* own, const uint64_t* opp, int32_t max_n,
                            const uint32_t* n_dev, float* logits, float* value, void* stream) {

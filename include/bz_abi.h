@@ -242,7 +242,8 @@ typedef struct bz_engine_cfg {
  * child's old subtree node for node (deterministic PUCT on the same evaluations), so about the played move's share of the
  * previous search's visits -- a quarter at cfg 3 -- never reaches the net again.  The new tree is still built from scratch
  * (this is NOT subtree reuse: no statistic is kept, DESIGN.md 3.10 stays an option of its own): results are bit for bit
- * those without any cache.  counters[9] = the part of counters[8] that came from the previous search. */
+ * those without any cache.  counters[9] = the part of counters[8] that came from the previous search.  Nothing is carried
+ * over a change of weights: a search that follows bz_net_update / bz_engine_set_net starts with the in-search cache only. */
 #define BZ_ENGINE_EVAL_CACHE_CARRY 4u
 
 /* offsets (bytes, from the workspace base) of the caller-visible arrays */

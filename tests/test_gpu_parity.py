@@ -1148,6 +1148,38 @@ def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, s
     assert cc["n_cache_hits_prev"] > 0.05 * c0["n_net_leaves"] and frac_c > frac_s + 0.05
 
 
+def test_evaluation_cache_carries_nothing_across_a_weight_update():
+    """the carried-over part of the evaluation cache holds evaluations of the PREVIOUS search's weights: after
+    DeviceNet.update (bz_net_update: refresh_device_net between two iterations on a live engine) the next search must not
+    take them.  Two engines on one net (cache with carry-over / no cache): search, move, new weights, search, move, search --
+    root statistics bit for bit the same after every search; the search right after the update has no carried-over hit,
+    the one after that has them again."""
+    from betazero_amd.net import DeviceNet
+    B, sims = 32, 200
+    m1, m2 = _net(128, 6, bf16=True), _net(128, 6, seed=5, bf16=True)
+    dn = DeviceNet.from_module(m1, B)
+    kw = dict(net=dn, temp_moves=8, openings=1, seed=4, rounds=2, stagger=40)
+    on, off = _engine("reversi", B, sims, "net_bf16", eval_cache=True, **kw), _engine("reversi", B, sims, "net_bf16", eval_cache=False, **kw)
+    for e in (on, off):
+        e.reset_games(); e.reset_counters()
+    prev_hits = []
+    for mv in range(4):
+        if mv == 2:
+            torch.cuda.synchronize()
+            dn.update(m2.flat_params())
+        before = on.counters()["n_cache_hits_prev"]
+        for e in (on, off):
+            e.search()
+        prev_hits.append(on.counters()["n_cache_hits_prev"] - before)
+        (N1, W1, P1), (N0, W0, P0) = on.root_stats(), off.root_stats()
+        assert np.array_equal(N1, N0), mv
+        assert np.array_equal(W1.view(np.uint32), W0.view(np.uint32)) and np.array_equal(P1.view(np.uint32), P0.view(np.uint32)), mv
+        for e in (on, off):
+            e.play(True)
+    assert on.status() == off.status()
+    assert prev_hits[0] == 0 and prev_hits[1] > 0 and prev_hits[2] == 0 and prev_hits[3] > 0, prev_hits
+
+
 def test_cfg3_800_sims_bf16_net_search_close_to_oracle_bf16_emulation():
     """one 800-simulation search with the bf16 MFMA net in the loop vs the oracle running the same
     search with its bf16-emulating net (CPU threads, 8 games).  The two nets differ by ~6e-4 on the logits
