@@ -120,7 +120,7 @@ def launch_ranks(n, argv):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(cmd, env=env, stdout=_JSON_FD)  # (the parent's own descriptor 1 is stderr by now: claim_stdout)
 
 
 def rehearsal(args, rank, world):
@@ -168,7 +168,7 @@ def rehearsal(args, rank, world):
                                    "device_name": "cpu (rehearsal)", "device_uuid": "", "games_finished": float(n_games), "seconds": dt,
                                    "pid": os.getpid()})
     if rank == 0:
-        print(json.dumps({"metric": "selfplay_games_per_s", "value": None, "unit": "games/s", "n_gpus": dist.get_world_size(),
+        emit_json({"metric": "selfplay_games_per_s", "value": None, "unit": "games/s", "n_gpus": dist.get_world_size(),
                           "steps": K, "warmup": args.warmup or 0, "ms_per_step": float(t[0]) / K * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                           "data": "synthetic", "rehearsal": True,
@@ -177,7 +177,7 @@ def rehearsal(args, rank, world):
                           "ranks": {"backend": "gloo", "world_size": world, "distinct_devices": 0, "per_rank": ranks},
                           "collectives": len(calls), "allocations_in_timed_region": allocs, "block_bytes_per_rank": int(buf.nbytes),
                           "gathered_bytes": int(gathered.numel()), "pooled_rows": int(rows),
-                          "pooled_games": int(sum(h["n_games"] for h in heads))}))
+                          "pooled_games": int(sum(h["n_games"] for h in heads))})
 
 
 def usable_cores():
@@ -818,6 +818,28 @@ def run_reversi(ctx, args, B, sims, K, W):
     return out
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """keep the process's stdout for the ONE JSON line: RCCL prints a version banner on stdout when the first communicator is
+    built (seen on the box: five lines before the JSON of a --force-collective run), and any other native library may do the
+    same.  From here on file descriptor 1 is stderr for everybody; emit_json writes to the saved descriptor."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
     # multi-process GPU work on this image needs dmabuf IPC (the host driver does not support the legacy mode: RCCL set-up and
     # tensor sharing otherwise fail with "hipIpcGetMemHandle: invalid argument"); the image exports this already -- make sure a
@@ -860,6 +882,7 @@ def main():
     ap.add_argument("--ttt-lanes", type=int, default=0, choices=[-1, 0, 1, 2, 4, 8],
                     help="--workload ttt: lanes per game of the fused search (bz_engine_cfg.ttt_lanes; 0 = default, -1 = generic kernel)")
     args = ap.parse_args()
+    claim_stdout()
 
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
@@ -991,7 +1014,7 @@ def main():
         assert out["n_gpus"] == args.gpus
         if args.force_collective:
             out["forced_collective_path"] = True
-        print(json.dumps(out))
+        emit_json(out)
     if ctx.dist:
         dist.destroy_process_group()
 

@@ -1948,8 +1948,10 @@ def test_bench_multi_gpu_branch_runs_under_rccl_at_world_size_1(launcher):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    # stdout is the ONE JSON line and nothing else (RCCL's version banner, printed on stdout when the communicator is built,
+    # must not land in front of it: bench.py keeps descriptor 1 for the line)
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["forced_collective_path"] is True and out["value"] > 0
     rk = out["ranks"]
