@@ -1097,8 +1097,9 @@ def test_cfg3_full_size_4096_games_800_sims_bf16_net_invariants(ev, B, stagger):
         assert evals < cnt["n_sims"] + roots
 
 
-@pytest.mark.parametrize("ev,game,B,sims", [("net_bf16", "reversi", 384, 800), ("net_f32", "reversi6", 40, 300), ("net_fp8", "reversi", 300, 200)],
-                         ids=["bf16_800", "f32_6x6_300", "fp8_200"])
+@pytest.mark.parametrize("ev,game,B,sims", [("net_bf16", "reversi", 384, 800), ("net_f32", "reversi6", 40, 300), ("net_fp8", "reversi", 300, 200),
+                                            ("net_f32", "reversi4", 64, 300)],
+                         ids=["bf16_800", "f32_6x6_300", "fp8_200", "f32_4x4_300"])
 def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, sims):
     """BZ_ENGINE_EVAL_CACHE (+ _CARRY): a leaf whose position was evaluated earlier in the same search -- or, with carry-over,
     in the slot's previous search -- takes that node's priors and value instead of an evaluator row.  Three engines on the
@@ -1115,7 +1116,8 @@ def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, s
         from betazero_amd.quant import fake_quantize_fp8_
         fake_quantize_fp8_(mod)
     dn = DeviceNet.from_module(mod, B)
-    kw = dict(net=dn, temp_moves=8, openings=1, seed=2, rounds=2, stagger=58 if game == "reversi" else 20)
+    # (4x4: games of at most 12 plies, most of a 300-simulation tree is terminal nodes and repeats -- the table's worst case)
+    kw = dict(net=dn, temp_moves=8, openings=1, seed=2, rounds=2, stagger={"reversi": 58, "reversi6": 20, "reversi4": 6}[game])
     engs = [_engine(game, B, sims, ev, eval_cache=mode, **kw) for mode in (True, "search", False)]
     for e in engs:
         e.reset_games(); e.reset_counters()
@@ -1146,6 +1148,36 @@ def test_evaluation_cache_changes_no_result_and_saves_evaluations(ev, game, B, s
           f"evaluations shared = {frac_s:.3f}; with carry-over {cc['n_cache_hits']} ({cc['n_cache_hits_prev']} from the previous search) = {frac_c:.3f}")
     assert frac_s > (0.03 if sims >= 300 else 0.01)   # (a 200-simulation tree meets fewer transpositions than an 800-simulation one)
     assert cc["n_cache_hits_prev"] > 0.05 * c0["n_net_leaves"] and frac_c > frac_s + 0.05
+
+
+def test_mcts_player_with_the_evaluation_cache_searches_like_an_engine_without():
+    """the plug-in's path (bz_engine_set_roots per move, one game, a search every second ply of the game): two MCTSPlayers --
+    cache with carry-over, the default -- play 16 plies; before every move a cache-less engine searches the same position:
+    the player's visit counts are the engine's, bit for bit, and from each player's second move on part of its evaluations
+    come from its previous search (the opponent's reply was one of the children it had searched)."""
+    import betazero_amd as bz
+    from betazero_amd.net import DeviceNet
+    sims = 200
+    dn = DeviceNet.from_module(_net(128, 6, bf16=True), 1)
+    players = {1: bz.MCTSPlayer(1, sims=sims, net=dn), -1: bz.MCTSPlayer(-1, sims=sims, net=dn)}
+    ref = _engine("reversi", 1, sims, "net_bf16", net=dn, eval_cache=False)
+    b, side, carried = bz.ReversiBoard(), 1, 0
+    for ply in range(16):
+        if not b.generate_possible_moves(side):
+            side = -side
+            continue
+        mv = players[side].get_move(b)
+        own, opp = b.bits(side)
+        ref.set_roots([own], [opp], [side]); ref.search()
+        N, _, _ = ref.root_stats()
+        assert np.array_equal(players[side].last_visits, N[0]), ply
+        b = b.make_move(mv[0], mv[1], side)
+        side = -side
+    for pl in players.values():
+        c = pl._engine("reversi").counters()
+        assert c["n_net_leaves"] + c["n_cache_hits"] == c["n_expanded"]
+        carried += c["n_cache_hits_prev"]
+    assert carried > 0
 
 
 def test_evaluation_cache_carries_nothing_across_a_weight_update():
