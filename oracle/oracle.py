@@ -222,6 +222,18 @@ def mcts_search_nodes(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=
     return o[:n], p[:n], t[:n]
 
 
+def mcts_search_walkstats(game, own, opp, to_move, sims, eval_kind, c_puct=1.5, net=None):
+    """diagnostic: per-level statistics of one search's walks (bz_oracle.c orc_mcts_search_walkstats)"""
+    out = np.zeros(7, np.uint64)
+    L = lib()
+    L.orc_mcts_search_walkstats.restype = C.c_int
+    L.orc_mcts_search_walkstats.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    if L.orc_mcts_search_walkstats(game, int(own), int(opp), to_move, sims, eval_kind, c_puct, net.h if net else None, out.ctypes.data) < 0:
+        raise ValueError("terminal root")
+    k = ("sims", "levels", "fav_hits", "levels_below_root", "fav_hits_below_root", "round_trips_with_prefetch")
+    return {n: int(out[i]) for i, n in enumerate(k)}
+
+
 def selfplay_game(game, gid, sims, eval_kind, temp_moves=0, openings=0, seed=0, c_puct=1.5, net=None,
                   max_moves=0, dir_alpha=0.0, dir_eps=0.0, reuse=False):
     na = 9 if game == GAME_TTT else 65
