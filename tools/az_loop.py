@@ -106,6 +106,7 @@ def main():
         plies = sp.run_iteration()
         ex = sp.device_examples()    # finished games' rows, packed on the device
         winners, _ = sp.winners()
+        cnt = sp.counters()
         torch.cuda.synchronize()
         t_play = time.time() - t0
         t1 = time.time()
@@ -143,6 +144,8 @@ def main():
                              "after": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in val_after.items() if k != "rows"}},
               "self_play_x_wins": int((winners > 0).sum()), "self_play_o_wins": int((winners < 0).sum()),
               "self_play_s": round(t_play, 1), "games_per_s": round(args.games / t_play, 1), "train_s": round(t_train, 1),
+              "mean_walk_nodes": round(cnt["n_path_nodes"] / max(1, cnt["n_sims"]), 2),
+              "evaluations_shared": round(cnt["n_cache_hits"] / max(1, cnt["n_cache_hits"] + cnt["n_net_leaves"]), 3),
               "arena": arena("net_bf16", dnet)})
     for d in (int(x) for x in args.final_depths.split(",") if x):
         emit({"what": "final arena", "opponent_depth": d, "sims": args.arena_sims, "trained": arena("net_bf16", dnet, d),
