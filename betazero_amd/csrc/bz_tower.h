@@ -130,7 +130,7 @@ template <int C_, int P_ = 512 / C_, bool M16_ = false> struct Tw {
 #if defined(BZ_EXP_STAMPS) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_STAMPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
-#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER) || defined(BZ_EXP_MFMA16) || defined(BZ_EXP_MFMA_AMAJOR)) && !defined(BZ_EXPERIMENT)
+#if (defined(BZ_EXP_NOPS) || defined(BZ_EXP_NOP1) || defined(BZ_EXP_NO_ROWT) || defined(BZ_EXP_NO_LAYER_BARRIER) || defined(BZ_EXP_MFMA16) || defined(BZ_EXP_MFMA_AMAJOR) || defined(BZ_EXP_EPILOGUE_HALF)) && !defined(BZ_EXPERIMENT)
 #error "BZ_EXP_NOPS is a diagnostic variant: build it through betazero_amd.build.build_variant()"
 #endif
 // weight-fragment loads of the bf16 tower.  Diagnostic option BZ_EXP_WEIGHTS_NT: non-temporal loads, to see whether the
@@ -530,8 +530,13 @@ __device__ __forceinline__ void epilogue16(f32x16 (&acc)[G::MW][G::NU], char* ou
     for (int a = 0; a < 2; ++a) {
         const int slot = G::pos16(4 * wt + 2 * a + (g >> 1), x);
         const f32x4 bq = bias.q[0][a];
+#ifdef BZ_EXP_EPILOGUE_HALF  // TIMING ONLY (results are wrong): what hiding half of the epilogue behind MFMAs could gain at most
+        constexpr int kB0 = 1;
+#else
+        constexpr int kB0 = 0;
+#endif
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = kB0; b < 2; ++b)
 #pragma unroll
             for (int par = 0; par < 2; ++par)
 #pragma unroll
