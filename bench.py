@@ -24,8 +24,9 @@ evaluation: the engine's evaluation cache, BZ_ENGINE_EVAL_CACHE(_CARRY).  The tr
 still built from scratch for every move.  Results are bit for bit those
 without it, the tree is the same tree; `roofline` counts only the rows the net
 really computed, the line says how many evaluations were shared, and
-`secondary.cfg3_no_eval_cache` / `--no-eval-cache` run the same workload with every
-leaf through the net.)
+`secondary.cfg3_no_eval_cache` / `--eval-cache off` run the same workload with every
+leaf through the net, `secondary.cfg3_eval_cache_in_search_only` / `--eval-cache search`
+with repeats inside one search shared only.)
 A "step" (ttt) = one complete iteration: all 65,536 games played to the end.
 
 N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL), games sharded
@@ -628,7 +629,7 @@ def run_reversi(ctx, args, B, sims, K, W):
     sp = PipelinedSelfPlay("reversi", B, sims, "net_" + prec, net, pipelines=NS, game_id_base=ctx.rank * B,
                            game_id_stride=ctx.world * B, device=ctx.dev, temp_moves=8, openings=1, seed=0, rounds=rounds,
                            stagger=PLIES_PER_GAME if steady else 0, reuse_subtree=args.reuse_subtree, run_ahead=args.run_ahead,
-                           eval_cache=not args.no_eval_cache,
+                           eval_cache=False if args.no_eval_cache else ("search" if args.eval_cache == "search" else True),
                            dirichlet_alpha=0.5 if args.dirichlet_eps > 0 else 0.0, dirichlet_eps=args.dirichlet_eps)
     engs, Bs = sp.engines, sp.sizes[0]
     sp.reset_games()
@@ -731,7 +732,8 @@ def run_reversi(ctx, args, B, sims, K, W):
            "config": {"workload": f"reversi8x8_{B}games_{sims}sims_convnet6x128_{prec}",
                       "games_per_gpu": B, "sims_per_move": sims, "c_puct": 1.5, "temp_moves": 8, "openings": 12,
                       "evaluator": "policy/value conv tower 6x128 (226.86 MFLOP per leaf), random init seed 0",
-                      "evaluation_cache": ({"on": True, "evaluations_shared": cnt["n_cache_hits"],
+                      "evaluation_cache": ({"on": True, "scope": "inside a search only" if args.eval_cache == "search" else "inside a search + the slot's previous search",
+                                            "evaluations_shared": cnt["n_cache_hits"],
                                             "of_which_from_the_previous_search": cnt["n_cache_hits_prev"], "evaluations_computed": cnt["n_net_leaves"],
                                             "shared_fraction": cnt["n_cache_hits"] / max(1, cnt["n_cache_hits"] + cnt["n_net_leaves"]),
                                             "note": "a position met again inside one search, or evaluated by the slot's previous search (after a move the "
@@ -870,6 +872,9 @@ def main():
                          "the thread then spins on the runtime's full queue, a whole core per rank)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --games per GPU (default, the headline); strong = --games in total, split over the ranks")
+    ap.add_argument("--eval-cache", default="carry", choices=["carry", "search", "off"],
+                    help="the engine's evaluation cache: carry = inside a search + from the slot's previous search (default), search = "
+                         "inside a search only, off = every leaf through the net (= --no-eval-cache); results are identical in all three")
     ap.add_argument("--no-eval-cache", action="store_true",
                     help="every non-terminal leaf through the net, repeats of a position inside one search included (the engine's "
                          "evaluation cache off; results are identical either way)")
@@ -883,6 +888,8 @@ def main():
                     help="--workload ttt: lanes per game of the fused search (bz_engine_cfg.ttt_lanes; 0 = default, -1 = generic kernel)")
     args = ap.parse_args()
     claim_stdout()
+    if args.eval_cache == "off":
+        args.no_eval_cache = True
 
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
@@ -972,6 +979,7 @@ def main():
                 a_fp8 = argparse.Namespace(**{**vars(args), "precision": "fp8", "mode": "steady"})
                 a_iter = argparse.Namespace(**{**vars(args), "mode": "iteration"})
                 a_nocache = argparse.Namespace(**{**vars(args), "no_eval_cache": True, "mode": "steady"})
+                a_insearch = argparse.Namespace(**{**vars(args), "eval_cache": "search", "mode": "steady"})
                 for name, fn in (
                         # cfg 5 as SURVEY 7 reads it: the fp8 net as the in-loop evaluator of 8192 concurrent games
                         ("cfg5_selfplay", lambda: run_reversi(ctx, a_fp8, 8192, sims, 6, 2)),
@@ -980,6 +988,8 @@ def main():
                         ("cfg3_iteration", lambda: run_reversi(ctx, a_iter, games, sims, 1, 0)),
                         # the headline workload with every leaf through the net (evaluation cache off): same results, more rows
                         ("cfg3_no_eval_cache", lambda: run_reversi(ctx, a_nocache, games, sims, 4, 1)),
+                        # ... and with the cache restricted to repeats INSIDE one search (nothing taken from the previous search)
+                        ("cfg3_eval_cache_in_search_only", lambda: run_reversi(ctx, a_insearch, games, sims, 4, 1)),
                         ("cfg2", lambda: run_ttt(ctx, 65536, 50, 20, 2)),
                         ("cfg5", lambda: run_net(ctx, 8192, 1000, 50, True)),
                         ("env_step", lambda: run_env(ctx, 1 << 26, 20, 3)),
