@@ -179,8 +179,8 @@ def test_bench_gpus_n_starts_its_own_ranks_cpu_rehearsal(world):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
                         "--games", "64"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout  # stdout is the line and nothing else (bench.claim_stdout)
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["rehearsal"] is True and out["collectives"] == 1
     assert out["allocations_in_timed_region"] == []  # nothing is allocated between t0 and dt
