@@ -95,6 +95,7 @@ _SIGS = {
     "bz_engine_destroy": (i32, [vp]),
     "bz_engine_get_layout": (i32, [vp, C.POINTER(EngineLayout)]),
     "bz_engine_set_net": (i32, [vp, vp]),
+    "bz_engine_debug_set_search_seq": (i32, [vp, C.c_uint32]),
     "bz_engine_reset_games": (i32, [vp, vp]),
     "bz_engine_set_roots": (i32, [vp, vp, vp, vp, vp]),
     "bz_engine_search": (i32, [vp, vp]),

@@ -1579,6 +1579,16 @@ BZ_EXPORT int32_t bz_engine_set_net(bz_engine* e, bz_net* net) {
     return BZ_OK;
 }
 
+/* test hook: the number of searches begun so far, as the evaluation cache counts them (its generation stamp cycles through
+ * 1 .. 2^19 - 2).  Lets a test start an engine just below the wrap instead of running half a million searches. */
+BZ_EXPORT int32_t bz_engine_debug_set_search_seq(bz_engine* e, uint32_t seq) {
+    BZ_REQUIRE(e, "null engine");
+    BZ_REQUIRE(seq < kTtGenMax - 1u, "bz_engine_debug_set_search_seq: 0 <= seq <= 2^19 - 3");
+    e->search_seq = seq;
+    e->eval_epoch = 0;  // nothing is carried over from before the jump
+    return BZ_OK;
+}
+
 BZ_EXPORT int32_t bz_engine_reset_counters(bz_engine* e, void* stream) {
     BZ_REQUIRE(e, "null engine");
     BZ_HIP(hipMemsetAsync(e->dev.counters, 0, kCntWords * 8, (hipStream_t)stream));

@@ -275,6 +275,9 @@ int32_t bz_engine_create(const bz_engine_cfg* cfg, void* workspace, int64_t work
 int32_t bz_engine_destroy(bz_engine* e);
 int32_t bz_engine_get_layout(const bz_engine* e, bz_engine_layout* out);
 int32_t bz_engine_set_net(bz_engine* e, bz_net* net);
+/* test hook: set the count of searches begun so far (0 .. 2^19 - 3) -- the evaluation cache stamps its entries with it, cycling
+ * through 1 .. 2^19 - 2; a test starts just below the wrap with this.  Nothing is carried over the jump. */
+int32_t bz_engine_debug_set_search_seq(bz_engine* e, uint32_t seq);
 /* start every slot at the game's start position (round 0) */
 int32_t bz_engine_reset_games(bz_engine* e, void* stream);
 /* load arbitrary root positions (MCTSPlayer.get_move, the arena, tests): device arrays [B];

@@ -1180,6 +1180,35 @@ def test_mcts_player_with_the_evaluation_cache_searches_like_an_engine_without()
     assert carried > 0
 
 
+def test_evaluation_cache_generation_stamp_wraps_cleanly():
+    """the cache stamps its entries with the search count modulo 2^19 - 2 (19 bits beside the 13-bit node id).  An engine
+    started three searches below the wrap (test hook bz_engine_debug_set_search_seq) plays six moves across it: same root
+    statistics as an engine without the cache after every search, and carried-over hits in every search but the first --
+    the search with stamp 1 takes the tree of stamp 2^19 - 2 as its previous one."""
+    from betazero_amd import _lib
+    from betazero_amd.net import DeviceNet
+    B, sims = 32, 200
+    dn = DeviceNet.from_module(_net(128, 6, bf16=True), B)
+    kw = dict(net=dn, temp_moves=8, openings=1, seed=6, rounds=2, stagger=40)
+    on, off = _engine("reversi", B, sims, "net_bf16", eval_cache=True, **kw), _engine("reversi", B, sims, "net_bf16", eval_cache=False, **kw)
+    _lib.check(_lib.lib().bz_engine_debug_set_search_seq(on.h, (1 << 19) - 2 - 3))
+    for e in (on, off):
+        e.reset_games(); e.reset_counters()
+    prev_hits = []
+    for mv in range(6):
+        before = on.counters()["n_cache_hits_prev"]
+        for e in (on, off):
+            e.search()
+        prev_hits.append(on.counters()["n_cache_hits_prev"] - before)
+        (N1, W1, P1), (N0, W0, P0) = on.root_stats(), off.root_stats()
+        assert np.array_equal(N1, N0), mv
+        assert np.array_equal(W1.view(np.uint32), W0.view(np.uint32)) and np.array_equal(P1.view(np.uint32), P0.view(np.uint32)), mv
+        for e in (on, off):
+            e.play(True)
+    assert on.status() == off.status()
+    assert prev_hits[0] == 0 and all(h > 0 for h in prev_hits[1:]), prev_hits
+
+
 def test_evaluation_cache_carries_nothing_across_a_weight_update():
     """the carried-over part of the evaluation cache holds evaluations of the PREVIOUS search's weights: after
     DeviceNet.update (bz_net_update: refresh_device_net between two iterations on a live engine) the next search must not
