@@ -116,7 +116,7 @@ struct Cnt { u32 v[CNT_N]; };
 // Diagnostic build only (betazero_amd.build.build_variant("treestamps", ["-DBZ_EXP_TREE_STAMPS"]), tools/exp_tree_stamps.py):
 // shader-clock stamps between the phases of k_tree_step, summed over all waves into counters[16..23].  The product build
 // compiles the empty struct away.
-#if defined(BZ_EXP_TREE_STAMPS) || defined(BZ_EXP_NO_COOP_ENV)
+#if defined(BZ_EXP_TREE_STAMPS) || defined(BZ_EXP_NO_COOP_ENV) || defined(BZ_EXP_TT_WEAK_HASH)
 #ifndef BZ_EXPERIMENT
 #error "BZ_EXP_* are diagnostic options: build them through betazero_amd.build.build_variant()"
 #endif
@@ -358,7 +358,13 @@ __device__ __forceinline__ u32 group_min_u32(u32 x) {
 template <int kGW>
 __device__ __forceinline__ bool tt_lookup_insert(const EngineDev& E, int g, int sub, u64 own, u64 opp, u32 gen, u32 prev_nodes,
                                                  u32 new_id, u32& src, u32& src_e0) {
+#ifdef BZ_EXP_TT_WEAK_HASH
+    // TEST BUILD ONLY (tests/test_gpu_parity.py): every position has tag 0 and lives in one of two buckets -- tag matches that
+    // are NOT the position and full buckets become the normal case; the results must still be those without any cache
+    const u64 h = hash_pos(own, opp) & 1u;
+#else
     const u64 h = hash_pos(own, opp);
+#endif
     const u32 tag = (u32)(h >> 32);
     const u32 gen_prev = gen == 1u ? kTtGenMax - 1u : gen - 1u;  // (the host's counter cycles 1 .. 2^19 - 2)
     u64* bucket = E.tt + ((size_t)g * (size_t)E.tt_buckets + (size_t)(h & (u64)(E.tt_buckets - 1))) * 16;

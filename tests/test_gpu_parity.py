@@ -1180,6 +1180,52 @@ def test_mcts_player_with_the_evaluation_cache_searches_like_an_engine_without()
     assert carried > 0
 
 
+def test_evaluation_cache_with_a_degenerate_hash_changes_nothing_either():
+    """"a tag match is confirmed against the stored node's position; a full bucket just means no insertion" -- exercised: a
+    test build of the library (-DBZ_EXP_TT_WEAK_HASH: every position has tag 0 and one of two buckets, so nearly every
+    lookup meets a tag match that is NOT its position, and the buckets are full after 32 nodes) runs the cache-on engine
+    against the cache-off engine in a child process: root statistics, moves and example rows bit for bit the same over
+    three moves."""
+    import subprocess
+    import sys
+    from betazero_amd import build
+    so = build.build_variant("ttweak", ["-DBZ_EXP_TT_WEAK_HASH"])
+    script = """
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+from betazero_amd.engine import SelfPlayEngine
+from betazero_amd.net import DeviceNet, PolicyValueNet
+from betazero_amd import _lib
+assert b"TT_WEAK_HASH" in _lib.lib().bz_build_info(), _lib.lib().bz_build_info()
+torch.manual_seed(0)
+dn = DeviceNet.from_module(PolicyValueNet(128, 6, 64).round_to_bf16_(), 64)
+kw = dict(net=dn, temp_moves=8, openings=1, seed=3, rounds=2, stagger=50)
+on = SelfPlayEngine("reversi", 64, 300, "net_bf16", eval_cache=True, **kw)
+off = SelfPlayEngine("reversi", 64, 300, "net_bf16", eval_cache=False, **kw)
+for e in (on, off):
+    e.reset_games(); e.reset_counters()
+for mv in range(3):
+    for e in (on, off):
+        e.search()
+    (N1, W1, P1), (N0, W0, P0) = on.root_stats(), off.root_stats()
+    assert np.array_equal(N1, N0) and np.array_equal(W1.view(np.uint32), W0.view(np.uint32)) and np.array_equal(P1.view(np.uint32), P0.view(np.uint32)), mv
+    for e in (on, off):
+        e.play(True)
+assert on.status() == off.status()
+a, b = on.example_tensors(), off.example_tensors()
+for f in ("own", "opp", "act", "mover", "len"):
+    assert torch.equal(a[f], b[f]), f
+assert torch.equal(a["pi"].view(torch.int32), b["pi"].view(torch.int32))
+c1, c0 = on.counters(), off.counters()
+assert c1["n_net_leaves"] + c1["n_cache_hits"] == c0["n_net_leaves"]
+print("hits", c1["n_cache_hits"], "of", c0["n_net_leaves"])
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, BZ_HIP_SO=so, BZ_ALLOW_EXPERIMENT="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.startswith("hits "), r.stdout
+
+
 def test_evaluation_cache_generation_stamp_wraps_cleanly():
     """the cache stamps its entries with the search count modulo 2^19 - 2 (19 bits beside the 13-bit node id).  An engine
     started three searches below the wrap (test hook bz_engine_debug_set_search_seq) plays six moves across it: same root
