@@ -35,9 +35,9 @@ struct ProfScope {
 };
 }  // namespace bz
 
-// bz_net.hip: forward over the first *n_dev (device counter, <= max_n) positions; n_dev may be null
 // bz_net.hip: which parameter upload the net's weights are from (changes with every bz_net_create / bz_net_update)
 uint64_t bz_net_epoch(const bz_net* net);
+// bz_net.hip: forward over the first *n_dev (device counter, <= max_n) positions; n_dev may be null
 int32_t bz_net_forward_dev(bz_net* net, int bf16, const uint64_t* own, const uint64_t* opp, int32_t max_n,
                            const uint32_t* n_dev, float* logits, float* value, void* stream);
 
